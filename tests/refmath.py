@@ -1,0 +1,64 @@
+"""Independent formulation of the fused conv, used only to pin the C oracle.
+
+Works from plain OIHW weights (so it also checks the OIhw4i16o4i reorder),
+computes exact accumulators with torch float64 conv2d (exact: |acc| < 2**53) and
+performs the requantisation with numpy float32 element-wise ops (one rounding per
+op, no FMA), following SURVEY.md 8(a) "Intended semantics".
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from cases import F32, S32, S8, U8, UNDEF
+
+
+def _acc_conv(src_nhwc, w_oihw, stride, pad):
+    x = torch.from_numpy(src_nhwc.astype(np.float64)).permute(0, 3, 1, 2)
+    w = torch.from_numpy(w_oihw.astype(np.float64))
+    y = F.conv2d(x, w, stride=stride, padding=pad)          # zero padding
+    return y.permute(0, 2, 3, 1).contiguous().numpy().astype(np.int64)
+
+
+def _cvt_x86(f, rm):
+    """vcvtps2dq: RNE or floor; NaN / out of range -> 0x80000000."""
+    r = np.floor(f) if rm == 1 else np.rint(f)
+    bad = ~((f >= np.float32(-2147483648.0)) & (f < np.float32(2147483648.0)))
+    out = np.where(bad, 0.0, r).astype(np.int64)
+    out[bad] = -2147483648
+    return out
+
+
+def _requant(acc, bias, scales, relu):
+    f = acc.astype(np.float32)                               # int -> f32, RNE
+    if bias is not None:
+        f = f + bias.astype(np.float32)
+    f = f * scales.astype(np.float32)
+    if relu:
+        f = np.where(np.float32(0) > f, np.float32(0), f)    # vmaxps(zero, f)
+    return f.astype(np.float32)
+
+
+def _store(f, dt, rm):
+    if dt == F32:
+        return f
+    v = _cvt_x86(f, rm)
+    if dt == S32:
+        return v.astype(np.int32)
+    if dt == S8:
+        return np.clip(v, -128, 127).astype(np.int8)
+    return np.where((v < 0) | (v > 255), 255, v).astype(np.uint8)   # unsigned saturate of the bits
+
+
+def conv_ref(case, data):
+    acc0 = _acc_conv(data["src"], data["w0"], case.stride, case.pad)
+    fused = case.oc1x1 > 0
+    relu0 = fused or case.relu0 or case.dst_dt == U8
+    f0 = _requant(acc0, data["bia0"], data["scales0"], relu0)
+    if not fused:
+        return _store(f0, case.dst_dt, case.rm0)
+    mid = _store(f0, U8, case.rm0).astype(np.int64)
+    w1 = data["w1"].reshape(case.oc1x1, case.oc).astype(np.int64)
+    acc1 = mid @ w1.T
+    relu1 = case.relu1 or case.dst_dt == U8
+    f1 = _requant(acc1, data["bia1"], data["scales1"], relu1)
+    return _store(f1, case.dst_dt, case.rm1)
