@@ -1,0 +1,562 @@
+// dfx_api.hip -- host side of the C ABI declared in include/dfx.h.
+//
+// Host-side counterparts of the reference's op drivers:
+//   validation        op_conv<T>::init_conf + jit_conv_kernel::init_conf
+//                     (/root/reference/src/op_conv.cc:262-365, src/jit_conv_kernel.cc:512-673)
+//   workspace/buffers op_conv<T>::op_conv (src/op_conv.h:70-95), util/memory.cc:21-40
+//   dispatch          op_conv<T>::infer (src/op_conv.cc:22-29) -> ONE kernel launch
+//   concat            op_concat<T> (src/op_concat.h:28-61), jit_concat_kernel::init_conf
+//                     (src/jit_concat_kernel.cc:130-197)
+// No CPU compute path exists here: without a usable HIP device every compute
+// entry point returns an error.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "conv_mfma.cuh"
+#include "dfx_device.cuh"
+
+namespace dfx {
+int launch_conv_generic(const ConvArgs &a, hipStream_t s, int *grid_out, int *lds_out);
+#define DFX_DECL(n) \
+  int launch_conv_mfma_##n(const ConvArgs &, const MfmaGeom &, int, int, int, int, int, hipStream_t, int)
+DFX_DECL(f32);
+DFX_DECL(s32);
+DFX_DECL(s8);
+DFX_DECL(u8);
+#undef DFX_DECL
+
+int launch_concat(const ConcatArgs &a, hipStream_t s);
+}  // namespace dfx
+
+using namespace dfx;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      return fail(e_ == hipErrorNoDevice ? DFX_ERR_NO_DEVICE : DFX_ERR_HIP, "%s: %s",   \
+                  #expr, hipGetErrorString(e_));                                        \
+  } while (0)
+
+static size_t dt_size(int dt) { return (dt == DFX_F32 || dt == DFX_S32) ? 4 : 1; }
+
+struct dfx_conv {
+  dfx_conv_desc d;
+  int variant;
+  ConvArgs args;
+  MfmaGeom geom;
+  int icb, ocb, G, grid, block, lds;
+  void *d_wei, *d_wei1, *d_consts;
+  size_t wei_bytes, wei1_bytes, consts_count;
+  bool weights_set;
+  void *d_src, *d_dst;  // lazily allocated for dfx_conv_submit_host
+  hipStream_t host_stream;
+  char kernel_name[96];
+};
+
+struct dfx_concat {
+  dfx_concat_desc d;
+  std::vector<int> channels;
+  ConcatArgs args;
+  std::vector<void *> d_srcs;  // lazily allocated for submit_host
+  void *d_dst;
+  hipStream_t host_stream;
+};
+
+extern "C" {
+
+int dfx_version(void) { return DFX_VERSION; }
+const char *dfx_last_error(void) { return g_err; }
+
+int dfx_device_count(int *count) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) n = 0;
+  if (count) *count = n;
+  return DFX_OK;
+}
+
+int dfx_set_device(int ordinal) {
+  HIP_TRY(hipSetDevice(ordinal));
+  return DFX_OK;
+}
+
+int dfx_device_name(char *buf, size_t len) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  hipDeviceProp_t p;
+  HIP_TRY(hipGetDeviceProperties(&p, dev));
+  snprintf(buf, len, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+  return DFX_OK;
+}
+
+int dfx_mem_alloc_host(void **p, size_t bytes) {
+  HIP_TRY(hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault));
+  return DFX_OK;
+}
+int dfx_mem_free_host(void *p) {
+  if (p) HIP_TRY(hipHostFree(p));
+  return DFX_OK;
+}
+int dfx_mem_alloc_device(void **p, size_t bytes) {
+  HIP_TRY(hipMalloc(p, bytes ? bytes : 1));
+  return DFX_OK;
+}
+int dfx_mem_free_device(void *p) {
+  if (p) HIP_TRY(hipFree(p));
+  return DFX_OK;
+}
+int dfx_memcpy_h2d(void *dst, const void *src, size_t bytes, dfx_stream_t s) {
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)s));
+  return DFX_OK;
+}
+int dfx_memcpy_d2h(void *dst, const void *src, size_t bytes, dfx_stream_t s) {
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)s));
+  return DFX_OK;
+}
+int dfx_memset_device(void *dst, int value, size_t bytes, dfx_stream_t s) {
+  HIP_TRY(hipMemsetAsync(dst, value, bytes, (hipStream_t)s));
+  return DFX_OK;
+}
+int dfx_stream_create(dfx_stream_t *s) {
+  hipStream_t st;
+  HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  *s = st;
+  return DFX_OK;
+}
+int dfx_stream_destroy(dfx_stream_t s) {
+  if (s) HIP_TRY(hipStreamDestroy((hipStream_t)s));
+  return DFX_OK;
+}
+int dfx_stream_sync(dfx_stream_t s) {
+  HIP_TRY(hipStreamSynchronize((hipStream_t)s));
+  return DFX_OK;
+}
+
+size_t dfx_blocked_offset(int o, int i, int kh, int kw, int I, int KH, int KW) {
+  // [o/16][i/16][kh][kw][(i%16)/4][o%16][i%4], jit_conv_kernel.cc:333-338
+  const size_t nb_ic = (size_t)I / 16;
+  return ((((size_t)(o / 16) * nb_ic + (size_t)(i / 16)) * KH + kh) * KW + kw) * 256 +
+         (size_t)((i % 16) / 4) * 64 + (size_t)(o % 16) * 4 + (size_t)(i % 4);
+}
+
+int dfx_reorder_oihw_to_blocked(const int8_t *oihw, int8_t *blocked, int O, int I, int KH,
+                                int KW) {
+  if (!oihw || !blocked || O <= 0 || I <= 0 || O % 16 || I % 16 || KH <= 0 || KW <= 0)
+    return fail(DFX_ERR_INVALID, "reorder: O and I must be positive multiples of 16");
+  for (int o = 0; o < O; ++o)
+    for (int i = 0; i < I; ++i)
+      for (int h = 0; h < KH; ++h)
+        for (int w = 0; w < KW; ++w)
+          blocked[dfx_blocked_offset(o, i, h, w, I, KH, KW)] =
+              oihw[(((size_t)o * I + i) * KH + h) * KW + w];
+  return DFX_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// conv
+// ---------------------------------------------------------------------------
+
+static int validate_conv(const dfx_conv_desc &d) {
+  auto is_dt = [](int v) { return v >= DFX_F32 && v <= DFX_U8; };
+  if (d.bs <= 0 || d.ic <= 0 || d.oc <= 0 || d.ih <= 0 || d.iw <= 0 || d.kh <= 0 || d.kw <= 0 ||
+      d.sh <= 0 || d.sw <= 0 || d.pad_t < 0 || d.pad_l < 0 || d.oc1x1 < 0)
+    return fail(DFX_ERR_INVALID, "conv: non-positive dimension");
+  if (!is_dt(d.dst_dt)) return fail(DFX_ERR_INVALID, "conv: bad dst dtype");  // jit_conv_kernel.cc:536-540
+  if (d.bia0_dt != DFX_UNDEF && !is_dt(d.bia0_dt)) return fail(DFX_ERR_INVALID, "conv: bad bias dtype");
+  if (d.bia1_dt != DFX_UNDEF && !is_dt(d.bia1_dt)) return fail(DFX_ERR_INVALID, "conv: bad bias1x1 dtype");
+  if (d.ic % 16 || d.oc % 16)  // jit_conv_kernel.cc:590-592
+    return fail(DFX_ERR_INVALID, "conv: ic and oc must be multiples of 16");
+  if (d.oh != (d.ih + 2 * d.pad_t - d.kh) / d.sh + 1 || d.ow != (d.iw + 2 * d.pad_l - d.kw) / d.sw + 1 ||
+      d.oh <= 0 || d.ow <= 0)  // op_conv.cc:290-297
+    return fail(DFX_ERR_INVALID, "conv: output image size do not match");
+  if (d.conv0_nscales != 1 && d.conv0_nscales != d.oc)  // op_conv.cc:311-313, :342-345
+    return fail(DFX_ERR_INVALID, "conv: conv0 scales count must be 1 or oc");
+  if (d.oc1x1) {
+    if (d.oc1x1 % 16) return fail(DFX_ERR_INVALID, "conv: oc1x1 must be a multiple of 16");  // :619-621
+    if (d.conv1_nscales != 1 && d.conv1_nscales != d.oc1x1)
+      return fail(DFX_ERR_INVALID, "conv: conv1 scales count must be 1 or oc1x1");
+  }
+  if (d.conv0_round_mode < 0 || d.conv0_round_mode > 1 || d.conv1_round_mode < 0 || d.conv1_round_mode > 1)
+    return fail(DFX_ERR_INVALID, "conv: bad round mode");
+  return DFX_OK;
+}
+
+static size_t round16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+// pick the unit decomposition of the MFMA variant; false if nothing fits LDS
+static bool pick_geometry(const dfx_conv_desc &d, MfmaGeom &g, int &lds) {
+  const int ICB = d.ic / 32, OCB = d.oc / 32, NCB = d.oc1x1 / 32;
+  const size_t fixed = (size_t)OCB * 9 * ICB * 1024 + (size_t)NCB * OCB * 1024 +
+                       round16((size_t)3 * (d.oc + d.oc1x1) * 4);
+  const size_t budgets[2] = {81920, 163840};  // two / one workgroup(s) per CU
+  // rows per unit wanted for parallelism: aim for >= ~1024 units
+  int th_par = (int)(((long long)d.bs * d.oh) / 1024);
+  if (th_par < 1) th_par = 1;
+  if (th_par < 2 && (long long)d.bs * d.oh / 2 >= 256) th_par = 2;
+  for (size_t budget : budgets) {
+    if (fixed >= budget) continue;
+    auto th_fit = [&](int tw) {
+      const size_t row = (size_t)(tw + 2) * d.ic;
+      long long t = (long long)((budget - fixed) / row) - 2;
+      return (int)(t > d.oh ? d.oh : t);
+    };
+    int th = th_fit(d.ow);  // mode A: full-width rows, linear pixel numbering
+    int tw = d.ow, linear = 1;
+    if (th < 2 && d.ow > 32) {  // mode B: split wide rows into 32-multiples
+      int tw_b = d.ow >= 128 ? 128 : (d.ow / 32) * 32;
+      int th_b = th_fit(tw_b);
+      if (th_b > th) { th = th_b; tw = tw_b; linear = 0; }
+    }
+    if (th < 1) continue;
+    if (th > th_par) th = th_par;
+    if (th > 16) th = 16;
+    g.th = th; g.tw = tw; g.linear = linear;
+    g.uy = (d.oh + th - 1) / th;
+    g.ux = (d.ow + tw - 1) / tw;
+    lds = (int)(fixed + (size_t)(th + 2) * (tw + 2) * d.ic);
+    return true;
+  }
+  return false;
+}
+
+static bool mfma_eligible(const dfx_conv_desc &d) {
+  return d.oc1x1 > 0 && d.kh == 3 && d.kw == 3 && d.sh == 1 && d.sw == 1 && d.pad_t <= 1 &&
+         d.pad_l <= 1 && (d.ic == 32 || d.ic == 64) && (d.oc == 32 || d.oc == 64) &&
+         d.oc1x1 % 32 == 0;
+}
+
+static int mfma_dispatch(dfx_conv *h, hipStream_t s, int mode) {
+  switch (h->d.dst_dt) {
+    case DFX_F32: return launch_conv_mfma_f32(h->args, h->geom, h->icb, h->ocb, h->G, h->grid, h->lds, s, mode);
+    case DFX_S32: return launch_conv_mfma_s32(h->args, h->geom, h->icb, h->ocb, h->G, h->grid, h->lds, s, mode);
+    case DFX_S8: return launch_conv_mfma_s8(h->args, h->geom, h->icb, h->ocb, h->G, h->grid, h->lds, s, mode);
+    case DFX_U8: return launch_conv_mfma_u8(h->args, h->geom, h->icb, h->ocb, h->G, h->grid, h->lds, s, mode);
+  }
+  return -1;
+}
+
+extern "C" {
+
+int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
+  if (!desc || !out) return fail(DFX_ERR_INVALID, "conv_create: null argument");
+  *out = nullptr;
+  int rc = validate_conv(*desc);
+  if (rc) return rc;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(DFX_ERR_NO_DEVICE, "conv_create: no HIP device (this library has no CPU path)");
+
+  dfx_conv *h = new (std::nothrow) dfx_conv();
+  if (!h) return fail(DFX_ERR_HIP, "out of host memory");
+  memset(static_cast<void *>(h), 0, sizeof(*h));
+  h->d = *desc;
+  const dfx_conv_desc &d = h->d;
+
+  ConvArgs &a = h->args;
+  a.bs = d.bs; a.ic = d.ic; a.ih = d.ih; a.iw = d.iw; a.oc = d.oc; a.oh = d.oh; a.ow = d.ow;
+  a.kh = d.kh; a.kw = d.kw; a.sh = d.sh; a.sw = d.sw; a.pt = d.pad_t; a.pl = d.pad_l;
+  a.oc1 = d.oc1x1; a.dst_dt = d.dst_dt; a.relu0 = d.conv0_relu; a.relu1 = d.conv1_relu;
+  a.rm0 = d.conv0_round_mode; a.rm1 = d.conv1_round_mode;
+
+  bool want_mfma = mfma_eligible(d) && d.force_variant != DFX_VARIANT_GENERIC;
+  if (d.force_variant == DFX_VARIANT_MFMA_FUSED && !mfma_eligible(d)) {
+    delete h;
+    return fail(DFX_ERR_UNSUPPORTED, "conv_create: shape not covered by the MFMA variant");
+  }
+  if (want_mfma && pick_geometry(d, h->geom, h->lds)) {
+    h->variant = DFX_VARIANT_MFMA_FUSED;
+    h->icb = d.ic / 32; h->ocb = d.oc / 32;
+    const int ncb = d.oc1x1 / 32;
+    h->G = (ncb % 4 == 0) ? 4 : (ncb % 2 == 0 ? 2 : 1);
+    h->grid = d.bs * h->geom.uy * h->geom.ux;
+    h->block = MFMA_THREADS;
+    a.rows_per_unit = h->geom.th;
+    a.units_per_image = h->geom.uy * h->geom.ux;
+    snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_mfma_fused_kernel<%d,%d,%d,%d>", h->icb,
+             h->ocb, h->G, d.dst_dt);
+    if (mfma_dispatch(h, nullptr, 1) != 0) {
+      delete h;
+      return fail(DFX_ERR_HIP, "conv_create: cannot raise dynamic LDS limit to %d bytes", h->lds);
+    }
+  } else {
+    h->variant = DFX_VARIANT_GENERIC;
+    h->block = 256;
+    launch_conv_generic(a, nullptr, &h->grid, &h->lds);
+    a.rows_per_unit = 0;
+    snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_generic_kernel<dt=%d>", d.dst_dt);
+  }
+  *out = h;
+  return DFX_OK;
+}
+
+static float bias_to_f32(const void *b, int dt, int c) {
+  switch (dt) {  // vcvtdq2ps after vpmovsxbd / vpmovzxbd / vmovups, jit_conv_kernel.cc:235-255
+    case DFX_F32: return ((const float *)b)[c];
+    case DFX_S32: return (float)((const int32_t *)b)[c];
+    case DFX_S8: return (float)((const int8_t *)b)[c];
+    case DFX_U8: return (float)((const uint8_t *)b)[c];
+  }
+  return 0.0f;
+}
+
+int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei, const void *bia0, const float *scales0,
+                         const int8_t *wei1, const void *bia1, const float *scales1) {
+  if (!h || !wei || !scales0) return fail(DFX_ERR_INVALID, "set_weights: null argument");
+  const dfx_conv_desc &d = h->d;
+  const bool fused = d.oc1x1 > 0;
+  if (fused && (!wei1 || !scales1)) return fail(DFX_ERR_INVALID, "set_weights: fused op needs wei1x1 and scales1");
+  if ((d.bia0_dt != DFX_UNDEF && !bia0) || (fused && d.bia1_dt != DFX_UNDEF && !bia1))
+    return fail(DFX_ERR_INVALID, "set_weights: bias dtype set but pointer is null");
+
+  const int OC = d.oc, OC1 = d.oc1x1, IC = d.ic;
+  const size_t nw0 = (size_t)OC * IC * d.kh * d.kw, nw1 = (size_t)OC1 * OC;
+  std::vector<int8_t> p0(nw0), p1(nw1 ? nw1 : 1);
+  std::vector<float> cst((size_t)3 * (OC + OC1), 0.0f);
+  int32_t *comp0 = reinterpret_cast<int32_t *>(cst.data());
+  float *b0 = cst.data() + OC, *s0 = cst.data() + 2 * OC;
+  int32_t *comp1 = reinterpret_cast<int32_t *>(cst.data() + 3 * OC);
+  float *b1 = cst.data() + 3 * OC + OC1, *s1 = cst.data() + 3 * OC + 2 * OC1;
+  for (int c = 0; c < OC; ++c) {
+    b0[c] = d.bia0_dt == DFX_UNDEF ? 0.0f : bias_to_f32(bia0, d.bia0_dt, c);
+    s0[c] = scales0[d.conv0_nscales > 1 ? c : 0];  // count 1 = broadcast (intended semantics)
+  }
+  for (int c = 0; c < OC1; ++c) {
+    b1[c] = d.bia1_dt == DFX_UNDEF ? 0.0f : bias_to_f32(bia1, d.bia1_dt, c);
+    s1[c] = scales1[d.conv1_nscales > 1 ? c : 0];
+  }
+
+  if (h->variant == DFX_VARIANT_MFMA_FUSED) {
+    const int ICB = h->icb, OCB = h->ocb, G = h->G, NCB = OC1 / 32;
+    // W0 fragments [r][tap][c][lane][16]: lane (rho = lane&31, hh = lane>>5), byte j
+    //   = W0[oc = 32r + rho][ic = 32c + 16hh + j][tap]
+    for (int r = 0; r < OCB; ++r)
+      for (int tap = 0; tap < 9; ++tap)
+        for (int c = 0; c < ICB; ++c)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 16; ++j) {
+              const int oc = 32 * r + (lane & 31), ic = 32 * c + 16 * (lane >> 5) + j;
+              p0[((((size_t)r * 9 + tap) * ICB + c) * 64 + lane) * 16 + j] =
+                  wei[dfx_blocked_offset(oc, ic, tap / 3, tap % 3, IC, 3, 3)];
+            }
+    // W1 fragments [cb][r][lane][16]: cb = cg*G + cc; lane (lam, hh); byte j = 4q + i
+    //   = W1[oc1 = 32G*cg + G*lam + cc][oc = 32r + 8q + 4hh + i]
+    for (int cb = 0; cb < NCB; ++cb)
+      for (int r = 0; r < OCB; ++r)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 16; ++j) {
+            const int cg = cb / G, cc = cb % G, lam = lane & 31, hh = lane >> 5;
+            const int oc1 = 32 * G * cg + G * lam + cc;
+            const int oc = 32 * r + 8 * (j >> 2) + 4 * hh + (j & 3);
+            p1[(((size_t)cb * OCB + r) * 64 + lane) * 16 + j] =
+                wei1[dfx_blocked_offset(oc1, oc, 0, 0, OC, 1, 1)];
+          }
+    // u8 -> s8 offset compensation: 128 * sum of the channel's weights
+    for (int oc = 0; oc < OC; ++oc) {
+      int32_t s = 0;
+      for (int ic = 0; ic < IC; ++ic)
+        for (int tap = 0; tap < 9; ++tap) s += wei[dfx_blocked_offset(oc, ic, tap / 3, tap % 3, IC, 3, 3)];
+      comp0[oc] = 128 * s;
+    }
+    for (int o1 = 0; o1 < OC1; ++o1) {
+      int32_t s = 0;
+      for (int oc = 0; oc < OC; ++oc) s += wei1[dfx_blocked_offset(o1, oc, 0, 0, OC, 1, 1)];
+      comp1[o1] = 128 * s;
+    }
+  } else {
+    memcpy(p0.data(), wei, nw0);
+    if (fused) memcpy(p1.data(), wei1, nw1);
+  }
+
+  if (!h->d_wei) {
+    HIP_TRY(hipMalloc(&h->d_wei, nw0));
+    HIP_TRY(hipMalloc(&h->d_wei1, nw1 ? nw1 : 16));
+    HIP_TRY(hipMalloc(&h->d_consts, cst.size() * 4));
+  }
+  HIP_TRY(hipMemcpy(h->d_wei, p0.data(), nw0, hipMemcpyHostToDevice));
+  if (nw1) HIP_TRY(hipMemcpy(h->d_wei1, p1.data(), nw1, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_consts, cst.data(), cst.size() * 4, hipMemcpyHostToDevice));
+  h->args.wei = (const int8_t *)h->d_wei;
+  h->args.wei1 = (const int8_t *)h->d_wei1;
+  h->args.consts = (const float *)h->d_consts;
+  h->weights_set = true;
+  return DFX_OK;
+}
+
+int dfx_conv_submit(dfx_conv_t *h, const void *src_dev, void *dst_dev, dfx_stream_t s) {
+  if (!h || !src_dev || !dst_dev) return fail(DFX_ERR_INVALID, "conv_submit: null argument");
+  if (!h->weights_set) return fail(DFX_ERR_STATE, "conv_submit: dfx_conv_set_weights not called");
+  h->args.src = (const uint8_t *)src_dev;
+  h->args.dst = dst_dev;
+  int rc;
+  if (h->variant == DFX_VARIANT_MFMA_FUSED)
+    rc = mfma_dispatch(h, (hipStream_t)s, 0);
+  else
+    rc = launch_conv_generic(h->args, (hipStream_t)s, nullptr, nullptr);
+  if (rc != 0) return fail(DFX_ERR_UNSUPPORTED, "conv_submit: no kernel instance for this op");
+  HIP_TRY(hipGetLastError());
+  return DFX_OK;
+}
+
+static size_t conv_src_bytes(const dfx_conv_desc &d) { return (size_t)d.bs * d.ih * d.iw * d.ic; }
+static size_t conv_dst_bytes(const dfx_conv_desc &d) {
+  return (size_t)d.bs * d.oh * d.ow * (d.oc1x1 ? d.oc1x1 : d.oc) * dt_size(d.dst_dt);
+}
+
+int dfx_conv_submit_host(dfx_conv_t *h, const void *src_host, void *dst_host) {
+  if (!h || !src_host || !dst_host) return fail(DFX_ERR_INVALID, "conv_submit_host: null argument");
+  const size_t sb = conv_src_bytes(h->d), db = conv_dst_bytes(h->d);
+  if (!h->d_src) {
+    HIP_TRY(hipMalloc(&h->d_src, sb));
+    HIP_TRY(hipMalloc(&h->d_dst, db));
+    HIP_TRY(hipStreamCreateWithFlags(&h->host_stream, hipStreamNonBlocking));
+  }
+  HIP_TRY(hipMemcpyAsync(h->d_src, src_host, sb, hipMemcpyHostToDevice, h->host_stream));
+  int rc = dfx_conv_submit(h, h->d_src, h->d_dst, h->host_stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(dst_host, h->d_dst, db, hipMemcpyDeviceToHost, h->host_stream));
+  HIP_TRY(hipStreamSynchronize(h->host_stream));
+  return DFX_OK;
+}
+
+int dfx_conv_query(const dfx_conv_t *h, dfx_conv_info *info) {
+  if (!h || !info) return fail(DFX_ERR_INVALID, "conv_query: null argument");
+  const dfx_conv_desc &d = h->d;
+  memset(info, 0, sizeof(*info));
+  info->variant = h->variant;
+  info->grid = h->grid; info->block = h->block; info->lds_bytes = h->lds;
+  info->rows_per_unit = h->variant == DFX_VARIANT_MFMA_FUSED ? h->geom.th : 0;
+  const uint64_t px = (uint64_t)d.bs * d.oh * d.ow;
+  const uint64_t mac = px * ((uint64_t)d.oc * d.ic * d.kh * d.kw + (uint64_t)d.oc1x1 * d.oc);
+  info->algorithmic_ops = 2 * mac;
+  info->algorithmic_bytes = conv_src_bytes(d) + conv_dst_bytes(d) +
+                            (uint64_t)d.oc * d.ic * d.kh * d.kw + (uint64_t)d.oc1x1 * d.oc;
+  snprintf(info->kernel_name, sizeof(info->kernel_name), "%s", h->kernel_name);
+  return DFX_OK;
+}
+
+int dfx_conv_destroy(dfx_conv_t *h) {
+  if (!h) return DFX_OK;
+  if (h->host_stream) (void)hipStreamDestroy(h->host_stream);
+  (void)hipFree(h->d_wei); (void)hipFree(h->d_wei1); (void)hipFree(h->d_consts);
+  (void)hipFree(h->d_src); (void)hipFree(h->d_dst);
+  delete h;
+  return DFX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// concat
+// ---------------------------------------------------------------------------
+
+int dfx_concat_create(const dfx_concat_desc *desc, dfx_concat_t **out) {
+  if (!desc || !out || !desc->channels) return fail(DFX_ERR_INVALID, "concat_create: null argument");
+  *out = nullptr;
+  const dfx_concat_desc &d = *desc;
+  if (d.n_inputs <= 0 || d.bs <= 0 || d.h <= 0 || d.w <= 0)
+    return fail(DFX_ERR_INVALID, "concat: non-positive dimension");
+  if (d.dt < DFX_F32 || d.dt > DFX_U8) return fail(DFX_ERR_INVALID, "concat: bad dtype");
+  if (d.n_inputs > CONCAT_MAX_INPUTS)
+    return fail(DFX_ERR_UNSUPPORTED, "concat: more than %d inputs", CONCAT_MAX_INPUTS);
+  const int blk = dt_size(d.dt) == 1 ? 16 : 4;  // jit_concat_kernel.cc:155-196
+  for (int i = 0; i < d.n_inputs; ++i)
+    if (d.channels[i] <= 0 || d.channels[i] % blk)
+      return fail(DFX_ERR_INVALID, "concat: channels of input %d not a multiple of %d", i, blk);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(DFX_ERR_NO_DEVICE, "concat_create: no HIP device (this library has no CPU path)");
+  dfx_concat *h = new (std::nothrow) dfx_concat();
+  if (!h) return fail(DFX_ERR_HIP, "out of host memory");
+  h->d = d;
+  h->channels.assign(d.channels, d.channels + d.n_inputs);
+  h->d.channels = h->channels.data();
+  h->d_dst = nullptr;
+  h->host_stream = nullptr;
+  ConcatArgs &a = h->args;
+  memset(&a, 0, sizeof(a));
+  const int per_chunk = 16 / (int)dt_size(d.dt);
+  int end = 0;
+  for (int i = 0; i < d.n_inputs; ++i) {
+    end += d.channels[i] / per_chunk;
+    a.chunk_end[i] = end;
+  }
+  a.n_inputs = d.n_inputs;
+  a.chunks_per_px = end;
+  a.total_chunks = (long long)d.bs * d.h * d.w * end;
+  a.dt = d.dt;
+  a.relu = d.post_relu;
+  *out = h;
+  return DFX_OK;
+}
+
+int dfx_concat_submit(dfx_concat_t *h, const void *const *srcs_dev, void *dst_dev, dfx_stream_t s) {
+  if (!h || !srcs_dev || !dst_dev) return fail(DFX_ERR_INVALID, "concat_submit: null argument");
+  for (int i = 0; i < h->d.n_inputs; ++i) {
+    if (!srcs_dev[i]) return fail(DFX_ERR_INVALID, "concat_submit: null input %d", i);
+    h->args.src[i] = (const unsigned char *)srcs_dev[i];
+  }
+  h->args.dst = (unsigned char *)dst_dev;
+  launch_concat(h->args, (hipStream_t)s);
+  HIP_TRY(hipGetLastError());
+  return DFX_OK;
+}
+
+int dfx_concat_submit_gathered(dfx_concat_t *h, const void *gathered_dev, const uint64_t *offsets,
+                               void *dst_dev, dfx_stream_t s) {
+  if (!h || !gathered_dev || !offsets || !dst_dev)
+    return fail(DFX_ERR_INVALID, "concat_submit_gathered: null argument");
+  const void *ptrs[CONCAT_MAX_INPUTS];
+  for (int i = 0; i < h->d.n_inputs; ++i) {
+    if (offsets[i] % 16) return fail(DFX_ERR_INVALID, "concat_submit_gathered: offset %d not 16-byte aligned", i);
+    ptrs[i] = (const unsigned char *)gathered_dev + offsets[i];
+  }
+  return dfx_concat_submit(h, ptrs, dst_dev, s);
+}
+
+int dfx_concat_submit_host(dfx_concat_t *h, const void *const *srcs_host, void *dst_host) {
+  if (!h || !srcs_host || !dst_host) return fail(DFX_ERR_INVALID, "concat_submit_host: null argument");
+  const size_t px = (size_t)h->d.bs * h->d.h * h->d.w, es = dt_size(h->d.dt);
+  size_t oc = 0;
+  for (int c : h->channels) oc += c;
+  if (h->d_srcs.empty()) {
+    h->d_srcs.resize(h->d.n_inputs, nullptr);
+    for (int i = 0; i < h->d.n_inputs; ++i) HIP_TRY(hipMalloc(&h->d_srcs[i], px * h->channels[i] * es));
+    HIP_TRY(hipMalloc(&h->d_dst, px * oc * es));
+    HIP_TRY(hipStreamCreateWithFlags(&h->host_stream, hipStreamNonBlocking));
+  }
+  for (int i = 0; i < h->d.n_inputs; ++i)
+    HIP_TRY(hipMemcpyAsync(h->d_srcs[i], srcs_host[i], px * h->channels[i] * es, hipMemcpyHostToDevice,
+                           h->host_stream));
+  int rc = dfx_concat_submit(h, (const void *const *)h->d_srcs.data(), h->d_dst, h->host_stream);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(dst_host, h->d_dst, px * oc * es, hipMemcpyDeviceToHost, h->host_stream));
+  HIP_TRY(hipStreamSynchronize(h->host_stream));
+  return DFX_OK;
+}
+
+int dfx_concat_destroy(dfx_concat_t *h) {
+  if (!h) return DFX_OK;
+  for (void *p : h->d_srcs) (void)hipFree(p);
+  (void)hipFree(h->d_dst);
+  if (h->host_stream) (void)hipStreamDestroy(h->host_stream);
+  delete h;
+  return DFX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,191 @@
+"""GPU parity tests (run with -m gpu on the MI355X box).  Every check goes
+through the C ABI of include/dfx.h and compares with the CPU oracle on the same
+seeded inputs.  Bars: bit-exact for u8/s8/s32 outputs; f32 outputs are also
+compared bit-for-bit (tolerance 0 ulp; north_star allows 1)."""
+import glob
+import os
+from dataclasses import replace
+
+import numpy as np
+import pytest
+
+import cases as C
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import hipref
+    return hipref
+
+
+FUSED_CASES = (C.dtype_matrix(C.SMALL) + C.option_sweep(C.SMALL) + C.option_sweep(C.SMALL64)
+               + C.dtype_matrix(C.REF_SHAPES[0]) + C.dtype_matrix(C.REF_SHAPES[1])
+               + [C.REF_SHAPES[2], C.CONFIG2, replace(C.CONFIG2, dst_dt=C.S32, wide=True),
+                  C.CONFIG3_SMALL, replace(C.CONFIG3_SMALL, dst_dt=C.U8, wide=True),
+                  replace(C.CONFIG3_SMALL, dst_dt=C.F32, per_channel1=True, relu1=False),
+                  replace(C.CONFIG3_SMALL, dst_dt=C.S8, relu1=False, wide=True, rm0=1, rm1=1),
+                  C.ConvCase("w96", 1, 64, 6, 96, 64, 128, dst_dt=C.S32),
+                  C.ConvCase("w40p0", 2, 32, 7, 40, 64, 96, pad=(0, 0), dst_dt=C.S32),
+                  C.ConvCase("p10", 1, 32, 9, 9, 32, 32, pad=(1, 0)),
+                  C.ConvCase("one", 1, 32, 3, 3, 32, 32, pad=(0, 0))])
+
+
+@pytest.mark.parametrize("case", FUSED_CASES, ids=lambda c: c.ident())
+def test_fused_auto_variant(hip, oracle, case):
+    data = C.generate(case)
+    got, info = hip.hip_conv(case, data)
+    assert info.variant == hip.dfa.VARIANT_MFMA_FUSED, info.kernel_name
+    hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), info.kernel_name.decode())
+
+
+GENERIC_CASES = (C.dtype_matrix(C.SMALL) + C.option_sweep(C.SMALL)
+                 + [C.unfused(c) for c in C.dtype_matrix(C.SMALL) + C.option_sweep(C.SMALL64)]
+                 + [C.CONFIG2, C.REF_SHAPES[0],
+                    C.ConvCase("s2", 1, 16, 11, 9, 48, 80, stride=(2, 2)),
+                    C.ConvCase("k5", 1, 16, 9, 9, 16, 16, k=(5, 5), pad=(2, 2)),
+                    C.ConvCase("k1", 2, 32, 5, 5, 32, 0, k=(1, 1), pad=(0, 0), dst_dt=C.S32),
+                    C.ConvCase("ic128", 1, 128, 6, 6, 80, 48, dst_dt=C.S32, wide=True)])
+
+
+@pytest.mark.parametrize("case", GENERIC_CASES, ids=lambda c: c.ident())
+def test_generic_variant(hip, oracle, case):
+    data = C.generate(case)
+    got, info = hip.hip_conv(case, data, force_variant=hip.dfa.VARIANT_GENERIC)
+    assert info.variant == hip.dfa.VARIANT_GENERIC
+    hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), info.kernel_name.decode())
+
+
+def test_host_buffer_path(hip, oracle):
+    """drop-in semantics of op::submit(): host pointers in, host pointers out."""
+    for case in (C.CONFIG2, C.unfused(C.SMALL)):
+        data = C.generate(case)
+        got, info = hip.hip_conv(case, data, host_path=True)
+        hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), "host path")
+
+
+def test_golden_vectors(hip):
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "conv_*.npz")))
+    assert files
+    for f in files:
+        z = np.load(f, allow_pickle=False)
+        case = C.ConvCase(**{k: (tuple(v.tolist()) if v.ndim else v.item())
+                             for k, v in ((k[5:], z[k]) for k in z.files if k.startswith("case_"))})
+        data = dict(src=z["src"], w0=z["w0"], w1=z["w1"] if "w1" in z.files else None,
+                    bia0=z["bia0"] if "bia0" in z.files else None,
+                    bia1=z["bia1"] if "bia1" in z.files else None,
+                    scales0=z["scales0"], scales1=z["scales1"])
+        for fv in (-1, hip.dfa.VARIANT_GENERIC):
+            got, info = hip.hip_conv(case, data, force_variant=fv)
+            hip.assert_bit_equal(got, z["dst"], os.path.basename(f) + " " + info.kernel_name.decode())
+
+
+def test_cvt_edge_cases(hip, oracle):
+    """NaN/overflow -> 0x80000000 (vcvtps2dq), -0.0 through vmaxps, on both variants."""
+    case = C.ConvCase("edge", 1, 32, 5, 5, 32, 32, dst_dt=C.S32, bia0_dt=C.UNDEF,
+                      bia1_dt=C.UNDEF, relu1=False, wide=True)
+    data = C.generate(case)
+    data["scales1"] = np.array([3.0e38], dtype=np.float32)
+    ref = hip.oracle_conv(oracle, case, data)
+    assert (ref == -2147483648).any()
+    for fv in (-1, hip.dfa.VARIANT_GENERIC):
+        hip.assert_bit_equal(hip.hip_conv(case, data, force_variant=fv)[0], ref, "overflow")
+    for dst_dt in (C.U8, C.S8):
+        c2 = replace(case, dst_dt=dst_dt)
+        ref = hip.oracle_conv(oracle, c2, data)
+        for fv in (-1, hip.dfa.VARIANT_GENERIC):
+            hip.assert_bit_equal(hip.hip_conv(c2, data, force_variant=fv)[0], ref, "overflow narrow")
+    case = C.ConvCase("negzero", 1, 32, 5, 5, 32, 32, dst_dt=C.F32, bia0_dt=C.UNDEF,
+                      bia1_dt=C.UNDEF, relu1=True)
+    data = C.generate(case)
+    data["scales1"] = np.array([-0.0], dtype=np.float32)
+    ref = hip.oracle_conv(oracle, case, data)
+    assert (ref.view(np.uint32) == 0x80000000).any()
+    for fv in (-1, hip.dfa.VARIANT_GENERIC):
+        hip.assert_bit_equal(hip.hip_conv(case, data, force_variant=fv)[0], ref, "-0.0")
+    data["scales0"] = np.array([np.nan], dtype=np.float32)       # NaN intermediate -> 255
+    ref = hip.oracle_conv(oracle, case, data)
+    for fv in (-1, hip.dfa.VARIANT_GENERIC):
+        hip.assert_bit_equal(hip.hip_conv(case, data, force_variant=fv)[0], ref, "nan")
+
+
+def test_full_size_config3(hip, oracle):
+    """BASELINE.json configs[2] at full size (N=128, 56x56, 64->64->256, s32 out):
+    complete comparison with the multi-threaded oracle plus the size-independent
+    property that images are independent (batch-sharding invariant)."""
+    case = replace(C.CONFIG3_SMALL, name="cfg3", bs=128)
+    data = C.generate(case)
+    got, info = hip.hip_conv(case, data)
+    assert info.variant == hip.dfa.VARIANT_MFMA_FUSED
+    hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), "config 3 full")
+    # shard invariance: images [40, 56) alone give the same bytes
+    sub = dict(data, src=data["src"][40:56])
+    got_sub, _ = hip.hip_conv(replace(case, bs=16), sub)
+    hip.assert_bit_equal(got_sub, got[40:56], "batch shard")
+
+
+def test_full_size_config5_rows(hip, oracle):
+    """configs[4] shape (224x224, 64->64->128, f32 out) at N=2: wide-row units."""
+    case = replace(C.CONFIG5_TINY, bs=2)
+    data = C.generate(case)
+    got, info = hip.hip_conv(case, data)
+    assert info.variant == hip.dfa.VARIANT_MFMA_FUSED
+    hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), "config 5")
+
+
+def test_concat(hip, oracle):
+    import torch
+    from test_oracle import CONCAT_SHAPES, CONCAT_NARROW, concat_inputs
+    for np_dt in (np.float32, np.int32, np.int8, np.uint8):
+        shapes = CONCAT_SHAPES + (CONCAT_NARROW if np_dt in (np.float32, np.int32) else [])
+        for sh in shapes:
+            for wide in (False, True):
+                srcs = concat_inputs(sh, np_dt, wide)
+                n, _, h, w = sh[0]
+                for relu in (True, False):
+                    op = hip.dfa.Concat(n, h, w, [s[1] for s in sh], np_dt, relu)
+                    ref = oracle.concat(srcs, relu)
+                    dsrcs = [torch.from_numpy(s).cuda() for s in srcs]
+                    dst = torch.empty(op.dst_shape, dtype=dsrcs[0].dtype, device="cuda")
+                    dst.view(torch.uint8).fill_(0xCD)
+                    op.submit(dsrcs, dst)
+                    torch.cuda.synchronize()
+                    hip.assert_bit_equal(dst.cpu().numpy(), ref, "concat dev")
+                    hip.assert_bit_equal(op.submit_host(srcs), ref, "concat host")
+                    op.close()
+
+
+def test_concat_golden(hip):
+    import torch
+    for np_dt in (np.float32, np.int32, np.int8, np.uint8):
+        z = np.load(os.path.join(os.path.dirname(__file__), "golden",
+                                 "concat_%s.npz" % np.dtype(np_dt).name), allow_pickle=False)
+        si = 0
+        while "s%d_src0" % si in z.files:
+            srcs = []
+            while "s%d_src%d" % (si, len(srcs)) in z.files:
+                srcs.append(z["s%d_src%d" % (si, len(srcs))])
+            n, h, w, _ = srcs[0].shape
+            for relu in (0, 1):
+                op = hip.dfa.Concat(n, h, w, [s.shape[3] for s in srcs], np_dt, bool(relu))
+                hip.assert_bit_equal(op.submit_host(srcs), z["s%d_relu%d_dst" % (si, relu)], "concat golden")
+                op.close()
+            si += 1
+
+
+def test_concat_gathered(hip, oracle):
+    """rank-major staging buffer as an all-gather leaves it."""
+    import torch
+    rng = np.random.default_rng(5)
+    shards = [rng.integers(0, 256, (3, 5, 7, c)).astype(np.uint8) for c in (32, 64, 16, 48)]
+    flat = np.concatenate([s.reshape(-1) for s in shards])
+    offs = np.cumsum([0] + [s.size for s in shards[:-1]]).tolist()
+    op = hip.dfa.Concat(3, 5, 7, [s.shape[3] for s in shards], np.uint8, True)
+    g = torch.from_numpy(flat).cuda()
+    dst = torch.empty(op.dst_shape, dtype=torch.uint8, device="cuda")
+    op.submit_gathered(g, offs, dst)
+    torch.cuda.synchronize()
+    hip.assert_bit_equal(dst.cpu().numpy(), oracle.concat(shards, True), "gathered")
