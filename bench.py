@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the fused int8 conv3x3+relu+conv1x1(+relu) block.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload res2a] [--dst s32]
+
+A "step" is one pass of the hot path (one dfx_conv_submit) over one batch of
+synthetic input already resident in HBM.  Default workload = BASELINE.json
+configs[2], the configuration the metric is quoted on: ResNet-50 res2a-style
+block, N=128 per GPU, 56x56, 64->64->256, u8 x s8, s32 output.  With N>1 GPUs
+(launched by torch.distributed.run, one rank per GPU) every rank processes its
+own 128 images -- images are independent, so the conv path has no collective --
+and the value is the whole-job aggregate ("scaling": "weak").  The RCCL
+all-gather + op_concat exchange of configs[3] is measured after the timed region
+and reported beside it (key "concat_allgather"), never inside `value`.
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     dominant kernel vs its binding roof (HBM for s32/f32 output),
+               achieved = algorithmic bytes per launch / mean launch duration
+               measured with HIP events on the launching stream
+  cpu_baseline the CPU oracle's AVX-512-VNNI/OpenMP port (or its scalar OpenMP
+               form) timed on this host's cores on a bounded sample
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+INT8_PEAK_TOPS = 5033.0    # dense: 2048 op/clk/SIMD (v_mfma_i32_32x32x32_i8 in 32 clk) x 1024 SIMDs x 2.4 GHz
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def workloads():
+    import cases as C
+    return {
+        # name: (case at per-GPU batch, description)
+        "res2a": (C.ConvCase("res2a", 128, 64, 56, 56, 64, 256, dst_dt=C.S32),
+                  "BASELINE configs[2]: N=128 56x56 64->64->256 u8xs8"),
+        "vgg": (C.ConvCase("vgg", 64, 64, 224, 224, 64, 128, dst_dt=C.F32),
+                "BASELINE configs[4]: N=64 224x224 64->64->128 u8xs8"),
+        "bringup": (C.ConvCase("bringup", 1, 32, 28, 28, 32, 64, dst_dt=C.U8),
+                    "BASELINE configs[1]: N=1 28x28 32->32->64 u8xs8"),
+    }
+
+
+def cpu_baseline(case, data, budget_s=12.0):
+    """Oracle port timed on the host cores on a bounded sample of the workload."""
+    from dataclasses import replace
+    from oracle import oracle as orc
+    import hipref
+    impl = "avx512" if orc.have_avx512_vnni() else "scalar_mt"
+    n = min(case.bs, 32 if impl == "avx512" else 4)
+    sub = dict(data, src=data["src"][:n])
+    c = replace(case, bs=n)
+    hipref.oracle_conv(orc, c, sub, impl)                     # warm-up
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        hipref.oracle_conv(orc, c, sub, impl)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or reps >= 100:
+            break
+    return {"value": round(n * reps / el, 2), "unit": "images/sec", "cores": orc.num_threads(),
+            "kind": "port",
+            "sample": "%d images x %d reps of the same workload, oracle impl=%s (%s)" % (
+                n, reps, impl,
+                "AVX-512 VNNI intrinsics mirroring the reference JIT, OpenMP over (n,oh)"
+                if impl == "avx512" else "scalar C, OpenMP over (n,oh)")}
+
+
+def load_traffic(workload, dst):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes, if any."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        t = json.load(open(path))
+        return t.get("%s-%s" % (workload, dst))
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="res2a")
+    ap.add_argument("--dst", default=None, help="override dst dtype: u8|s8|s32|f32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=-1, help="-1 auto, 0 generic, 1 mfma")
+    args = ap.parse_args()
+
+    import torch
+    import cases as C
+    import hipref
+    dfa = importlib.import_module("deep-fusion_amd")
+    from dataclasses import replace
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    assert world == args.gpus or world == 1 and args.gpus == 1, \
+        "launch N>1 with torch.distributed.run --nproc-per-node N"
+
+    case, desc = workloads()[args.workload]
+    if args.dst:
+        case = replace(case, dst_dt={"u8": C.U8, "s8": C.S8, "s32": C.S32, "f32": C.F32}[args.dst])
+    dst_name = C.NAME_OF[case.dst_dt]
+    case = replace(case, seed=1234 + rank)
+    data = C.generate(case)
+
+    op = hipref.make_conv(case, data, force_variant=args.variant)
+    info = op.info()
+    tdt = {C.F32: torch.float32, C.S32: torch.int32, C.S8: torch.int8, C.U8: torch.uint8}[case.dst_dt]
+    # rotate over a few src/dst pairs so no step is served from the 256 MiB Infinity Cache
+    dst_bytes = int(np.prod(op.dst_shape)) * torch.empty(0, dtype=tdt).element_size()
+    nbuf = max(2, min(4, int(1.5e9 // max(dst_bytes, 1))))
+    srcs = [torch.from_numpy(np.roll(data["src"], i, axis=0)).cuda() for i in range(nbuf)]
+    dsts = [torch.empty(op.dst_shape, dtype=tdt, device="cuda") for _ in range(nbuf)]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        op.submit(srcs[i % nbuf], dsts[i % nbuf])
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for i in range(args.steps):
+        op.submit(srcs[i % nbuf], dsts[i % nbuf])      # launches on torch's current stream
+    e1.record()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    kern_ms = e0.elapsed_time(e1) / args.steps        # mean launch duration, HIP events
+    if world > 1:
+        tt = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, kern_ms = float(tt[0]), float(tt[1])
+
+    # sanity: the timed path produced the oracle's bytes (first image, rank 0)
+    extra = {}
+    if rank == 0:
+        from oracle import oracle as orc
+        one = dict(data, src=data["src"][:1])
+        ref = hipref.oracle_conv(orc, replace(case, bs=1), one)
+        hipref.assert_bit_equal(dsts[0][:1].cpu().numpy(), ref, "bench output vs oracle")
+
+    # configs[3]: op_concat + RCCL all-gather, measured outside the timed region
+    if world > 1:
+        try:
+            extra["concat_allgather"] = bench_concat_allgather(dfa, torch, dist, dsts[0], world, rank)
+        except Exception as ex:  # never lose the main line
+            extra["concat_allgather"] = {"error": repr(ex)[:200]}
+
+    if rank == 0:
+        images = case.bs * world * args.steps
+        value = images / elapsed
+        alg_bytes, alg_ops = int(info.algorithmic_bytes), int(info.algorithmic_ops)
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        tops = alg_ops / (kern_ms * 1e-3) / 1e12
+        hbm_bound = case.dst_dt in (C.S32, C.F32)
+        out = {
+            "metric": "fused conv3x3+relu+conv1x1 int8 images/sec",
+            "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8*s8->s32 (int8 MFMA), f32 requant, %s out" % dst_name, "data": "synthetic",
+            "config": {"workload": "%s (%s), %s out" % (args.workload, desc, dst_name),
+                       "per_gpu_batch": case.bs, "global_batch": case.bs * world,
+                       "parallelism": "batch-sharded x%d, no data-path collective" % world,
+                       "kernel": info.kernel_name.decode(), "grid": info.grid,
+                       "lds_bytes": info.lds_bytes, "rows_per_unit": info.rows_per_unit},
+            "roofline": {"bound": "hbm" if hbm_bound else "mfma",
+                         "achieved": round(achieved if hbm_bound else tops, 2),
+                         "peak": HBM_PEAK_GBS if hbm_bound else INT8_PEAK_TOPS,
+                         "unit": "GB/s" if hbm_bound else "TOP/s",
+                         "frac": round((achieved / HBM_PEAK_GBS) if hbm_bound else (tops / INT8_PEAK_TOPS), 4),
+                         "traffic": load_traffic(args.workload, dst_name),
+                         "kernel_ms": round(kern_ms, 5),
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "algorithmic_ops_per_launch": alg_ops,
+                         "hbm_GBps": round(achieved, 2), "hbm_frac_of_8TBps": round(achieved / HBM_PEAK_GBS, 4),
+                         "int8_TOPs": round(tops, 2), "mfma_frac_of_int8_peak": round(tops / INT8_PEAK_TOPS, 4)},
+        }
+        out.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(case, data)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_concat_allgather(dfa, torch, dist, conv_out, world, rank, images=16, iters=5):
+    """Every rank contributes the conv output of its first `images` images as one
+    channel branch; all-gather (RCCL) + concat+relu kernel -> {images,h,w,world*C}."""
+    ddist = importlib.import_module("deep-fusion_amd.dist")
+    local = conv_out[:images].contiguous()
+    bs, h, w, c = local.shape
+    np_dt = {torch.int32: np.int32, torch.float32: np.float32, torch.int8: np.int8,
+             torch.uint8: np.uint8}[local.dtype]
+    op = dfa.Concat(bs, h, w, [c] * world, np_dt, True)
+    offs, total = ddist.gathered_offsets(bs, h, w, [c] * world, local.element_size())
+    dst = torch.empty((bs, h, w, c * world), dtype=local.dtype, device=local.device)
+    times = []
+    for it in range(iters + 2):
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        g = ddist.allgather_shards(local, [c] * world)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        op.submit_gathered(g, offs, dst)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        if it >= 2:
+            times.append((t1 - t0, t2 - t1))
+    # correctness of the exchange: channel block r of dst == relu(rank r's shard)
+    mine = dst[..., rank * c:(rank + 1) * c]
+    ok = bool(torch.equal(mine, torch.clamp(local, min=0) if local.dtype != torch.uint8 else local))
+    tt = torch.tensor([sum(t[0] for t in times) / len(times), sum(t[1] for t in times) / len(times),
+                       0.0 if ok else 1.0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return {"shard_bytes_per_rank": int(local.numel() * local.element_size()),
+            "allgather_ms": round(float(tt[0]) * 1e3, 4), "concat_relu_ms": round(float(tt[1]) * 1e3, 4),
+            "allgather_GBps_per_rank_in": round(total * (world - 1) / world / float(tt[0]) / 1e9, 2),
+            "correct": float(tt[2]) == 0.0}
+
+
+if __name__ == "__main__":
+    main()

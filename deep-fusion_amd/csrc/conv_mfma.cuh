@@ -6,43 +6,65 @@
 //   compute1x1_loop / store_1x1output  src/jit_conv_kernel.cc:143-191, :50-141
 //   infer_conv0conv1                   src/op_conv.cc:140-260
 //
-// Design (one workgroup = one "unit" = TH output rows x TW output columns of
-// one image; 4 waves; each wave walks 32-pixel tiles of the unit):
-//
+// Structure
+//  * PERSISTENT workgroups of 8 waves, two per CU (4 waves per SIMD, <= 128
+//    VGPRs: a single wave issues at most one VALU instruction every ~4-5 cycles,
+//    so the requant epilogue needs the occupancy).  The 3x3 and 1x1 weights,
+//    already packed in MFMA fragment order by the host, are copied to LDS ONCE
+//    per workgroup; the workgroup then pulls "units" (TH output rows x TW output
+//    columns of one image) from a device-side queue (one atomicAdd per unit, the
+//    balance211 of op_conv.cc:155-156 made dynamic).
+//  * Wave roles: waves 0..6 compute (each walks 32-pixel tiles of the unit);
+//    wave 7 is the LOADER: while the compute waves work on unit k it holds the
+//    whole input halo tile of unit k+1 in its own registers (global loads issued
+//    early), and writes it (xor 0x80, swizzled) to LDS between the two barriers
+//    that separate units.  Compute waves never wait on a global load.
 //  * conv0 is D0[oc][px] = sum_k W0[oc][k] * X[k][px] with
-//    v_mfma_i32_32x32x32_i8: the packed s8 weights are the A operand (rows =
-//    oc), the input pixels are the B operand (columns = px).  One MFMA eats 32
-//    input channels of one (kh,kw) tap.  Both operands come from LDS with
-//    ds_read_b128: the weight image is lane-linear (packed on the host), the
-//    input halo tile is stored [row][col][ic] with a 16-byte-chunk XOR swizzle so
-//    that the 64 B/pixel stride is bank-conflict free.
-//  * MFMA i8 is signed x signed.  Activations are stored in LDS as (u8 xor 0x80)
-//    = u8 - 128; the accumulators start at comp0[oc] = 128 * sum_k W0[oc][k], so
-//    the s32 result is exact.  Zero padding is the byte 0x80 (= real 0), which
-//    keeps one compensation constant valid at the borders.
+//    v_mfma_i32_32x32x32_i8: packed s8 weights are the A operand (rows = oc),
+//    input pixels the B operand (columns = px).  One MFMA eats 32 input channels
+//    of one (kh,kw) tap.  Both operands come from LDS with ds_read_b128: the
+//    weight image is lane-linear, the input halo tile is [row][col][ic] with a
+//    16-byte-chunk XOR swizzle that makes the 64 B/pixel stride conflict free.
+//  * MFMA i8 is signed x signed.  Activations sit in LDS as (u8 xor 0x80) =
+//    u8 - 128, the MFMA chain starts from the inline constant 0, and the
+//    compensation comp0[oc] = 128 * sum_k W0[oc][k] is added as an f32 right after
+//    the int->f32 conversion: both |raw acc| and |comp| are < 2^24 here (K <= 576),
+//    hence exactly representable, and the single f32 add of two exact values is
+//    the correctly rounded sum = exactly what vcvtdq2ps gives on the true s32
+//    accumulator.  Zero padding is the byte 0x80 (= real 0), which keeps one
+//    compensation constant valid at the borders.
 //  * After conv0 a lane holds, for its pixel, 16 accumulators per 32-oc block at
 //    oc = 32r + 8q + 4h + i (h = lane>>5).  They are requantised in registers
-//    (ReLU, scale, round, saturate to u8) and packed 4 per dword; those 16 bytes
-//    per block ARE the A-operand fragment of the 1x1 MFMA, because the 1x1
-//    weights were packed on the host in exactly this k order.  The intermediate
-//    activation never leaves the register file.
+//    (ReLU, scale, round, saturate to u8), packed 4 per dword, and those 16 bytes
+//    per block ARE the A fragment of the 1x1 MFMA because the host packed the
+//    1x1 weights in exactly this k order: the intermediate activation never
+//    leaves the register file (the reference keeps it in xmm registers,
+//    jit_conv_kernel.cc:275-277).
 //  * conv1 is D1[px][oc1] = sum_oc mid[px][oc] * W1[oc][oc1]: lane = output
 //    channel, registers = pixels, so bias/scale are per-lane constants.  The host
-//    also permutes which channel each MFMA column computes: in a group of G
+//    also permutes which channel each MFMA column computes: within a group of G
 //    column blocks lane L owns channels 32G*cg + G*L + {0..G-1}, so every pixel
 //    is written with one G*4-byte (s32/f32) or G-byte (s8/u8) store per lane
-//    and a half-wave writes 128*G (or 32*G) contiguous bytes: full HBM lines.
+//    and a half-wave writes 128*G (or 32*G) contiguous bytes: whole HBM lines.
+//  * Requantisation has two code paths selected by a wave-uniform flag the host
+//    sets: "fast" (both round modes nearest-even, and the host proved from the
+//    weights that no value can reach +-2^31 or be NaN, so the x86 overflow/NaN
+//    selects are dead) and "exact" (everything else).  Both are bit-identical
+//    to the reference arithmetic on the inputs they accept.
 //
-// Supported here: kh = kw = 3, stride 1, pad in {0,1}, ic/oc/oc1x1 multiples of
-// 32 (ic, oc <= 64 per instantiation list in conv_mfma_inst.inc).  Everything
-// else goes to conv_generic.hip.
+// Supported here: kh = kw = 3, stride 1, pad in {0,1}, ic/oc in {32,64}, oc1x1 a
+// multiple of 32.  Everything else goes to conv_generic.hip.
 #pragma once
+
+#include <type_traits>
 
 #include "dfx_device.cuh"
 
 namespace dfx {
 
-constexpr int MFMA_THREADS = 256;
+constexpr int MFMA_THREADS = 512;  // 8 waves: 7 compute + 1 loader
+constexpr int MFMA_CW = 7;         // compute waves
+constexpr int MFMA_LC = 22;        // 16-byte chunks the loader wave holds per lane (88 VGPRs)
 
 __device__ __forceinline__ v16i mfma_i8(v4i a, v4i b, v16i c) {
   return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
@@ -55,224 +77,400 @@ __device__ __forceinline__ int chunk_swizzle(int P) {
   return (P >> 1) & 7;  // CP == 8
 }
 
-// XCD-aware block remap (bijective form): blocks that share blockIdx%8 share an
-// XCD/L2; give each XCD a contiguous run of units so vertically adjacent units
-// (which share halo rows) hit the same L2.  Speed only, never correctness.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-  const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
-  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-}
-
-template <int DST> struct DstT;
-template <> struct DstT<DFX_F32> { typedef float type; };
-template <> struct DstT<DFX_S32> { typedef int type; };
-template <> struct DstT<DFX_S8> { typedef int8_t type; };
-template <> struct DstT<DFX_U8> { typedef uint8_t type; };
-
-// one pixel's G consecutive channels -> one store
-template <int DST, int G>
-__device__ __forceinline__ void store_group(void *dst, size_t elem, const float (&f)[G], int rm) {
-  if (DST == DFX_F32) {
-    float *p = reinterpret_cast<float *>(dst) + elem;
-    if (G == 4) *reinterpret_cast<v4f *>(p) = v4f{f[0], f[1], f[2], f[3]};
-    else if (G == 2) *reinterpret_cast<float2 *>(p) = float2{f[0], f[1]};
-    else p[0] = f[0];
-  } else if (DST == DFX_S32) {
-    int v[G];
-#pragma unroll
-    for (int c = 0; c < G; ++c) v[c] = cvt_x86_rt(f[c], rm);
-    int *p = reinterpret_cast<int *>(dst) + elem;
-    if (G == 4) *reinterpret_cast<v4i *>(p) = v4i{v[0], v[1], v[2], v[3]};
-    else if (G == 2) *reinterpret_cast<int2 *>(p) = int2{v[0], v[1]};
-    else p[0] = v[0];
-  } else {
-    unsigned pk = 0;
-#pragma unroll
-    for (int c = 0; c < G; ++c) {
-      const int v = cvt_x86_rt(f[c], rm);
-      const unsigned b = (DST == DFX_U8) ? sat_u8_bits(v) : ((unsigned)sat_s8(v) & 0xffu);
-      pk |= b << (8 * c);
-    }
-    uint8_t *p = reinterpret_cast<uint8_t *>(dst) + elem;
-    if (G == 4) *reinterpret_cast<unsigned *>(p) = pk;
-    else if (G == 2) *reinterpret_cast<unsigned short *>(p) = (unsigned short)pk;
-    else p[0] = (uint8_t)pk;
-  }
-}
-
-struct MfmaGeom {  // unit decomposition chosen by the host (dfx_api.cpp)
+struct MfmaGeom {  // unit decomposition chosen by the host (dfx_api.hip)
   int th, tw;      // unit size in output rows / columns
   int uy, ux;      // units per image along y / x
   int linear;      // 1: tw == ow, pixels of a unit are numbered linearly across rows
                    // 0: tw % 32 == 0, every 32-pixel tile lies inside one row
+  int total_units;
+  int row_chunks;   // (tw + 2) * (ic / 16)
+  int tile_chunks;  // (th + 2) * row_chunks
+  unsigned row_magic;  // ceil(2^32 / row_chunks): q / row_chunks == umulhi(q, row_magic)
+  int fast;            // 1: requant fast path is valid (see header comment)
+  int *queue;          // [0] next unit, [1] finished workgroups; both 0 between launches
+#ifdef DFX_STAMPS
+  unsigned long long *prof;  // diagnostic build only: [workgroup][wave][8] cycle sums
+#endif
 };
 
+#ifdef DFX_STAMPS
+// In-kernel stamps (diagnostic build only; never quote this build's run time).
+__device__ __forceinline__ unsigned long long dfx_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define DFX_STAMP(var) const unsigned long long var = dfx_stamp()
+#define DFX_ACC(slot, expr) prof_acc[slot] += (expr)
+#else
+#define DFX_STAMP(var)
+#define DFX_ACC(slot, expr)
+#endif
+
+// f32 value of an accumulator before scaling: vcvtdq2ps(acc) + bias, with the
+// u8->s8 compensation folded in as an exact f32 add (see header comment)
+__device__ __forceinline__ float acc_to_f32(int raw, float comp, float bias) {
+  return __fadd_rn(__fadd_rn(__int2float_rn(raw), comp), bias);
+}
+
+// ---- one pixel's G consecutive channels -> one store.  FAST: RNE, all values
+// finite and |f| < 2^31 (host-proven), so the x86 overflow/NaN selects are dead
+// and u8 output can use v_cvt_pk_u8_f32 (RNE + [0,255] saturation, probed on
+// gfx950: tools/probe/probe_valu.hip), which also subsumes the ReLU. ----
+template <int DST, int G, bool FAST>
+__device__ __forceinline__ void store_group(unsigned char *p, const int (&acc)[G],
+                                            const float (&cp)[G], const float (&bs)[G],
+                                            const float (&sc)[G], bool relu, int rm) {
+  float f[G];
+#pragma unroll
+  for (int c = 0; c < G; ++c) f[c] = __fmul_rn(acc_to_f32(acc[c], cp[c], bs[c]), sc[c]);
+  if (DST == DFX_F32) {
+#pragma unroll
+    for (int c = 0; c < G; ++c) f[c] = relu ? relu_x86(f[c]) : f[c];
+    if (G == 4) *reinterpret_cast<v4f *>(p) = v4f{f[0], f[1], f[2], f[3]};
+    else if (G == 2) *reinterpret_cast<float2 *>(p) = float2{f[0], f[1]};
+    else *reinterpret_cast<float *>(p) = f[0];
+  } else if (DST == DFX_S32) {
+    int v[G];
+#pragma unroll
+    for (int c = 0; c < G; ++c) {
+      if (FAST) v[c] = (int)__builtin_rintf(relu ? __builtin_fmaxf(f[c], 0.0f) : f[c]);
+      else v[c] = cvt_x86_rt(relu ? relu_x86(f[c]) : f[c], rm);
+    }
+    if (G == 4) *reinterpret_cast<v4i *>(p) = v4i{v[0], v[1], v[2], v[3]};
+    else if (G == 2) *reinterpret_cast<int2 *>(p) = int2{v[0], v[1]};
+    else *reinterpret_cast<int *>(p) = v[0];
+  } else {
+    unsigned pk = 0;
+#pragma unroll
+    for (int c = 0; c < G; ++c) {
+      if (FAST && DST == DFX_U8) {
+        pk = __builtin_amdgcn_cvt_pk_u8_f32(f[c], c, pk);
+      } else {
+        const float fr = relu ? (FAST ? __builtin_fmaxf(f[c], 0.0f) : relu_x86(f[c])) : f[c];
+        const int v = FAST ? (int)__builtin_rintf(fr) : cvt_x86_rt(fr, rm);
+        const unsigned b = (DST == DFX_U8) ? sat_u8_bits(v) : ((unsigned)sat_s8(v) & 0xffu);
+        pk |= b << (8 * c);
+      }
+    }
+    if (G == 4) *reinterpret_cast<unsigned *>(p) = pk;
+    else if (G == 2) *reinterpret_cast<unsigned short *>(p) = (unsigned short)pk;
+    else *p = (uint8_t)pk;
+  }
+}
+
 template <int ICB, int OCB, int G, int DST>
-__global__ __launch_bounds__(MFMA_THREADS, 2) void conv_mfma_fused_kernel(ConvArgs a, MfmaGeom g) {
+__global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvArgs a, MfmaGeom g) {
   constexpr int IC = 32 * ICB, OC = 32 * OCB, CP = IC / 16;
+  constexpr int ESZ = (DST == DFX_F32 || DST == DFX_S32) ? 4 : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int OC1 = a.oc1, NCB = OC1 >> 5, NCG = NCB / G;
   unsigned char *w0s = smem;                                   // [OCB][9][ICB][64 lanes][16 B]
   unsigned char *w1s = w0s + OCB * 9 * ICB * 1024;             // [NCB][OCB][64 lanes][16 B]
   float *cst = reinterpret_cast<float *>(w1s + NCB * OCB * 1024);
-  const int cst_bytes = (3 * (OC + OC1) * 4 + 15) & ~15;
+  const int cst_bytes = (3 * (OC + OC1) * 4 + 16 + 15) & ~15;  // +16: the queue slot
+  int *sh_next = reinterpret_cast<int *>(cst + 3 * (OC + OC1));
   unsigned char *ins = reinterpret_cast<unsigned char *>(cst) + cst_bytes;  // halo tile
 
   const int tid = threadIdx.x;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
+  const int LW = g.tw + 2;
   const int upi = g.uy * g.ux;
-  const int n = bid / upi, u = bid - n * upi;
-  const int uyi = u / g.ux, uxi = u - uyi * g.ux;
-  const int y0 = uyi * g.th, x0 = uxi * g.tw;
-  const int th = min(g.th, a.oh - y0), tw = min(g.tw, a.ow - x0);
 
-  // ---- stage weights + constants (already in fragment order: linear copy) ----
-  {
+  // ---- weights + constants: the host keeps them in ONE device buffer laid out
+  //      exactly like the LDS image [W0 fragments | W1 fragments | constants], so a
+  //      single linear copy stages them.  All global loads of a pass are issued
+  //      before the first LDS write: one memory round trip per 64 KB. ----
+  auto stage_weights = [&]() {
     const v4i *s = reinterpret_cast<const v4i *>(a.wei);
-    v4i *d = reinterpret_cast<v4i *>(w0s);
-    for (int i = tid; i < OCB * 9 * ICB * 64; i += MFMA_THREADS) d[i] = s[i];
-    s = reinterpret_cast<const v4i *>(a.wei1);
-    d = reinterpret_cast<v4i *>(w1s);
-    for (int i = tid; i < NCB * OCB * 64; i += MFMA_THREADS) d[i] = s[i];
-    for (int i = tid; i < 3 * (OC + OC1); i += MFMA_THREADS) cst[i] = a.consts[i];
-  }
-  // ---- stage the input halo tile: rows y0-pt .. +th+1, cols x0-pl .. +tw+1 ----
-  const int LW = tw + 2;
-  {
-    const uint8_t *src_n = a.src + (size_t)n * a.ih * a.iw * IC;
-    const v4i pad = v4i{(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
-    for (int lr = 0; lr < th + 2; ++lr) {
-      const int iy = y0 - a.pt + lr;
-      const bool rowok = iy >= 0 && iy < a.ih;
-      for (int c = tid; c < LW * CP; c += MFMA_THREADS) {
-        const int lc = c / CP, j = c % CP;
-        const int ix = x0 - a.pl + lc;
-        v4i v = pad;
-        if (rowok && ix >= 0 && ix < a.iw)
-          v = *reinterpret_cast<const v4i *>(src_n + ((size_t)iy * a.iw + ix) * IC + 16 * j) ^ pad;
-        const int P = lr * LW + lc;
-        *reinterpret_cast<v4i *>(ins + P * IC + 16 * (j ^ chunk_swizzle<CP>(P))) = v;
+    v4i *d = reinterpret_cast<v4i *>(smem);
+    const int total = OCB * 9 * ICB * 64 + NCB * OCB * 64 + (3 * (OC + OC1) * 4 + 15) / 16;
+    for (int base = 0; base < total; base += 8 * MFMA_THREADS) {
+      const int q0 = base + tid, last = total - 1;
+      const v4i t0 = s[min(q0 + 0 * MFMA_THREADS, last)];
+      const v4i t1 = s[min(q0 + 1 * MFMA_THREADS, last)];
+      const v4i t2 = s[min(q0 + 2 * MFMA_THREADS, last)];
+      const v4i t3 = s[min(q0 + 3 * MFMA_THREADS, last)];
+      const v4i t4 = s[min(q0 + 4 * MFMA_THREADS, last)];
+      const v4i t5 = s[min(q0 + 5 * MFMA_THREADS, last)];
+      const v4i t6 = s[min(q0 + 6 * MFMA_THREADS, last)];
+      const v4i t7 = s[min(q0 + 7 * MFMA_THREADS, last)];
+      d[min(q0 + 0 * MFMA_THREADS, last)] = t0;
+      d[min(q0 + 1 * MFMA_THREADS, last)] = t1;
+      d[min(q0 + 2 * MFMA_THREADS, last)] = t2;
+      d[min(q0 + 3 * MFMA_THREADS, last)] = t3;
+      d[min(q0 + 4 * MFMA_THREADS, last)] = t4;
+      d[min(q0 + 5 * MFMA_THREADS, last)] = t5;
+      d[min(q0 + 6 * MFMA_THREADS, last)] = t6;
+      d[min(q0 + 7 * MFMA_THREADS, last)] = t7;
+    }
+  };
+
+  if (wave == MFMA_CW) {
+    // =========================== loader wave ===========================
+    const v4i x80 = v4i{(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+    v4i pf[MFMA_LC];
+    // chunk q of a unit's halo tile: LDS row lr = q / row_chunks, chunk c within the row
+    auto load_chunk = [&](const uint8_t *src_n, int y0, int x0, int q) {
+      const int lr = (int)__umulhi((unsigned)q, g.row_magic);
+      const int c = q - lr * g.row_chunks;
+      const int iy = y0 + lr, ix = x0 + c / CP;
+      const bool ok = q < g.tile_chunks && iy >= 0 && iy < a.ih && ix >= 0 && ix < a.iw;
+      // branch-free: out-of-image chunks read offset 0 of the image and are zeroed
+      // (real 0).  32-bit offset off a uniform base.
+      const unsigned off = ok ? (unsigned)((iy * a.iw + ix) * IC + 16 * (c % CP)) : 0u;
+      const v4i v = *reinterpret_cast<const v4i *>(src_n + off);
+      return (ok ? v : v4i{0, 0, 0, 0}) ^ x80;  // stored form: u8 - 128; padding = 0x80
+    };
+    // LDS byte offset of chunk q (unit independent); chunks beyond the tile go to a
+    // 16-byte dump slot right behind it so the write loop needs no predicate
+    auto chunk_lds_off = [&](int q) {
+      const int lr = (int)__umulhi((unsigned)q, g.row_magic);
+      const int c = q - lr * g.row_chunks;
+      const int P = lr * LW + c / CP;
+      return q < g.tile_chunks ? P * IC + 16 * ((c % CP) ^ chunk_swizzle<CP>(P)) : g.tile_chunks * 16;
+    };
+    auto unit_origin = [&](int unit, const uint8_t *&src_n, int &y0, int &x0) {
+      const int n = unit / upi, u = unit - n * upi;
+      const int uyi = u / g.ux, uxi = u - uyi * g.ux;
+      y0 = uyi * g.th - a.pt;
+      x0 = uxi * g.tw - a.pl;
+      src_n = a.src + (size_t)n * a.ih * a.iw * IC;
+    };
+    // issue-early half: first 64*MFMA_LC chunks of a unit -> registers
+#define DFX_PREFETCH(UNIT)                                                              \
+  do {                                                                                  \
+    const uint8_t *src_n_;                                                              \
+    int y0_, x0_;                                                                       \
+    unit_origin((UNIT), src_n_, y0_, x0_);                                              \
+    int lq_ = lane; /* opaque: keep the per-chunk index math out of the LICM set */     \
+    asm volatile("" : "+v"(lq_));                                                       \
+    _Pragma("unroll") for (int i = 0; i < MFMA_LC; ++i) pf[i] =                         \
+        load_chunk(src_n_, y0_, x0_, lq_ + 64 * i);                                     \
+  } while (0)
+#ifdef DFX_STAMPS
+    unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    // Everything between barrier (B) of unit k and barrier (A) of unit k+1 is on
+    // the workgroup's critical path, so it is only the LDS writes themselves: the
+    // destination offsets are precomputed here, and the queue index is drawn one
+    // unit ahead (the device-scope atomic takes microseconds to return).
+    int wr_off[MFMA_LC];
+#pragma unroll
+    for (int i = 0; i < MFMA_LC; ++i) wr_off[i] = chunk_lds_off(lane + 64 * i);
+    int unit = blockIdx.x;
+    int nxt = 0;
+    if (lane == 0) nxt = (int)gridDim.x + atomicAdd(g.queue, 1);
+    if (unit < g.total_units) DFX_PREFETCH(unit);  // first tile's loads fly during the weight copy
+    stage_weights();
+    while (unit < g.total_units) {
+      DFX_STAMP(l0);
+#pragma unroll
+      for (int i = 0; i < MFMA_LC; ++i)   // write-late half of the staging
+        *reinterpret_cast<v4i *>(ins + wr_off[i]) = pf[i];
+      if (g.tile_chunks > 64 * MFMA_LC) {  // oversized tile: the rest is staged synchronously
+        const uint8_t *src_n; int y0, x0;
+        unit_origin(unit, src_n, y0, x0);
+        for (int q = 64 * MFMA_LC + lane; q < g.tile_chunks; q += 64)
+          *reinterpret_cast<v4i *>(ins + chunk_lds_off(q)) = load_chunk(src_n, y0, x0, q);
+      }
+      DFX_STAMP(l1);
+      if (lane == 0) *sh_next = nxt;
+      DFX_STAMP(l2);
+      __syncthreads();  // (A) tile and next-unit index visible to the compute waves
+      DFX_STAMP(l3);
+      const int next = *sh_next;
+      if (lane == 0) nxt = (int)gridDim.x + atomicAdd(g.queue, 1);  // for the unit after next
+      if (next < g.total_units) DFX_PREFETCH(next);
+      DFX_STAMP(l4);
+      __syncthreads();  // (B) compute waves are done reading the tile
+      DFX_STAMP(l5);
+      DFX_ACC(0, l1 - l0);  // LDS write (incl. wait for the prefetch loads)
+      DFX_ACC(1, l2 - l1);  // publish queue index
+      DFX_ACC(2, l3 - l2);  // barrier A
+      DFX_ACC(3, l4 - l3);  // issue prefetch
+      DFX_ACC(4, l5 - l4);  // barrier B = compute time of the unit
+      DFX_ACC(7, 1);
+      unit = next;
+    }
+#ifdef DFX_STAMPS
+    if (lane == 0)
+      for (int k = 0; k < 8; ++k) g.prof[((size_t)blockIdx.x * 8 + wave) * 8 + k] = prof_acc[k];
+#endif
+    // last workgroup out re-arms the queue for the next launch
+    if (lane == 0) {
+      const int done = atomicAdd(g.queue + 1, 1);
+      if (done == (int)gridDim.x - 1) {
+        atomicExch(g.queue, 0);
+        atomicExch(g.queue + 1, 0);
       }
     }
+#undef DFX_PREFETCH
+    return;
   }
-  __syncthreads();
 
-  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-  const int *comp0 = reinterpret_cast<const int *>(cst);
-  const float *bias0 = cst + OC, *scale0 = cst + 2 * OC;
-  const int *comp1 = reinterpret_cast<const int *>(cst + 3 * OC);
-  const float *bias1 = cst + 3 * OC + OC1, *scale1 = cst + 3 * OC + 2 * OC1;
+  // =========================== compute waves ===========================
+  stage_weights();
+  const int l31 = lane & 31, h = lane >> 5;
+  const float *comp0 = cst, *bias0 = cst + OC, *scale0 = cst + 2 * OC;
+  const float *comp1 = cst + 3 * OC, *bias1 = cst + 3 * OC + OC1, *scale1 = cst + 3 * OC + 2 * OC1;
   const bool relu1 = a.relu1 || DST == DFX_U8;
+  const bool fast = g.fast != 0;
+  const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned row_bytes = (unsigned)OC1 * ESZ;  // dst bytes per pixel
 
-  const int npx = th * tw;
-  const int tiles_per_row = (tw + 31) >> 5;
-  const int ntiles = g.linear ? (npx + 31) >> 5 : th * tiles_per_row;
+#ifdef DFX_STAMPS
+  unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  int unit = blockIdx.x;
+  while (unit < g.total_units) {
+    DFX_STAMP(c0);
+    __syncthreads();  // (A)
+    DFX_STAMP(c1);
+    DFX_ACC(0, c1 - c0);  // wait at barrier A
+    const int next = *sh_next;
 
-  for (int t = wave; t < ntiles; t += MFMA_THREADS / 64) {
-    // pixel of this lane (conv0 column) and the tile's output base
-    int ty, tx, nvalid;
-    size_t obase;  // dst pixel index of px_local == 0
-    if (g.linear) {
-      nvalid = min(32, npx - 32 * t);
-      const int pc = 32 * t + min(l31, nvalid - 1);
-      ty = pc / tw;
-      tx = pc - ty * tw;
-      obase = ((size_t)n * a.oh + y0) * a.ow + 32 * t;
-    } else {
-      const int tr = t / tiles_per_row, tc = t - tr * tiles_per_row;
-      nvalid = min(32, tw - 32 * tc);
-      ty = tr;
-      tx = 32 * tc + min(l31, nvalid - 1);
-      obase = ((size_t)n * a.oh + y0 + tr) * a.ow + x0 + 32 * tc;
-    }
-    const int Pb = ty * LW + tx;
-    // Lane-constant LDS offsets are made opaque once per tile: otherwise LICM
-    // hoists every weight / constant fragment read out of the tile loop and
-    // keeps >200 VGPRs live across it (spills).
-    int lane16 = lane * 16, h4 = 4 * h, lch = G * l31;
-    asm volatile("" : "+v"(lane16), "+v"(h4), "+v"(lch));
+    const int n = unit / upi, u = unit - n * upi;
+    const int uyi = u / g.ux, uxi = u - uyi * g.ux;
+    const int y0 = uyi * g.th, x0 = uxi * g.tw;
+    const int th = min(g.th, a.oh - y0), tw = min(g.tw, a.ow - x0);
+    const int npx = th * tw;
+    const int tiles_per_row = (tw + 31) >> 5;
+    const int ntiles = g.linear ? (npx + 31) >> 5 : th * tiles_per_row;
 
-    // ---- conv0: 9 taps x ICB k-steps x OCB row blocks ----
-    v16i acc0[OCB];
-#pragma unroll
-    for (int r = 0; r < OCB; ++r)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const v4i c = *reinterpret_cast<const v4i *>(comp0 + 32 * r + 8 * q + h4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc0[r][4 * q + i] = c[i];
+    for (int t = wave; t < ntiles; t += MFMA_CW) {
+      // pixel of this lane (conv0 column) and the tile's output base (wave-uniform)
+      int ty, tx, nvalid;
+      size_t obase;  // dst pixel index of px_local == 0
+      if (g.linear) {
+        nvalid = min(32, npx - 32 * t);
+        const int pc = 32 * t + min(l31, nvalid - 1);
+        ty = pc / tw;
+        tx = pc - ty * tw;
+        obase = ((size_t)n * a.oh + y0) * a.ow + 32 * t;
+      } else {
+        const int tr = t / tiles_per_row, tc = t - tr * tiles_per_row;
+        nvalid = min(32, tw - 32 * tc);
+        ty = tr;
+        tx = 32 * tc + min(l31, nvalid - 1);
+        obase = ((size_t)n * a.oh + y0 + tr) * a.ow + x0 + 32 * tc;
       }
+      const int Pb = ty * LW + tx;
+      // Lane-constant LDS offsets are made opaque once per tile: otherwise LICM
+      // hoists every weight / constant fragment read out of the tile loop and
+      // keeps >200 VGPRs live across it (spills).
+      int lane16 = lane * 16, h4 = 4 * h, lch = G * l31;
+      asm volatile("" : "+v"(lane16), "+v"(h4), "+v"(lch));
+
+      DFX_STAMP(c2);
+      // ---- conv0: 9 taps x ICB k-steps x OCB row blocks ----
+      v16i acc0[OCB];
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+      for (int r = 0; r < OCB; ++r) acc0[r] = zero16;
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int P = Pb + kh * LW + kw;
-        const int sw = chunk_swizzle<CP>(P);
-        const unsigned char *base = ins + P * IC;
+      for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int c = 0; c < ICB; ++c) {
-          const v4i b = *reinterpret_cast<const v4i *>(base + 16 * ((2 * c + h) ^ sw));
+        for (int kw = 0; kw < 3; ++kw) {
+          const int P = Pb + kh * LW + kw;
+          const int sw = chunk_swizzle<CP>(P);
+          const unsigned char *base = ins + P * IC;
 #pragma unroll
-          for (int r = 0; r < OCB; ++r) {
-            const v4i w = *reinterpret_cast<const v4i *>(
-                w0s + ((r * 9 + kh * 3 + kw) * ICB + c) * 1024 + lane16);
-            acc0[r] = mfma_i8(w, b, acc0[r]);
+          for (int c = 0; c < ICB; ++c) {
+            const v4i b = *reinterpret_cast<const v4i *>(base + 16 * ((2 * c + h) ^ sw));
+#pragma unroll
+            for (int r = 0; r < OCB; ++r) {
+              const v4i w = *reinterpret_cast<const v4i *>(
+                  w0s + ((r * 9 + kh * 3 + kw) * ICB + c) * 1024 + lane16);
+              acc0[r] = mfma_i8(w, b, acc0[r]);
+            }
           }
         }
-      }
 
-    // ---- requant 0 in registers -> A fragments of the 1x1 ----
-    v4i mid[OCB];
-#pragma unroll
-    for (int r = 0; r < OCB; ++r)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int ch = 32 * r + 8 * q + h4;
-        const v4f bs = *reinterpret_cast<const v4f *>(bias0 + ch);
-        const v4f sc = *reinterpret_cast<const v4f *>(scale0 + ch);
-        unsigned pk = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float f = requant(acc0[r][4 * q + i], bs[i], sc[i], true);
-          pk |= sat_u8_bits(cvt_x86_rt(f, a.rm0)) << (8 * i);
-        }
-        mid[r][q] = (int)(pk ^ 0x80808080u);
-      }
-
-    // ---- conv1 + requant 1 + store, G column blocks at a time ----
-    for (int cg = 0; cg < NCG; ++cg) {
-      const int chb = 32 * G * cg + lch;  // this lane's first channel in the group
-      v16i acc1[G];
-      float bs[G], sc[G];
-#pragma unroll
-      for (int cc = 0; cc < G; ++cc) {
-        const int c1 = comp1[chb + cc];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc1[cc][e] = c1;
-        bs[cc] = bias1[chb + cc];
-        sc[cc] = scale1[chb + cc];
-      }
+      DFX_STAMP(c3);
+      DFX_ACC(1, c3 - c2);  // conv0 MFMA issue
+      // ---- requant 0 in registers -> A fragments of the 1x1 ----
+      v4i mid[OCB];
 #pragma unroll
       for (int r = 0; r < OCB; ++r)
 #pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int ch = 32 * r + 8 * q + h4;
+          const v4f cp = *reinterpret_cast<const v4f *>(comp0 + ch);
+          const v4f bs = *reinterpret_cast<const v4f *>(bias0 + ch);
+          const v4f sc = *reinterpret_cast<const v4f *>(scale0 + ch);
+          unsigned pk = 0;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float f = __fmul_rn(acc_to_f32(acc0[r][4 * q + i], cp[i], bs[i]), sc[i]);
+            if (fast) pk = __builtin_amdgcn_cvt_pk_u8_f32(f, i, pk);  // ReLU + RNE + sat + pack
+            else pk |= sat_u8_bits(cvt_x86_rt(relu_x86(f), a.rm0)) << (8 * i);
+          }
+          mid[r][q] = (int)(pk ^ 0x80808080u);
+        }
+
+      DFX_STAMP(c4);
+      DFX_ACC(2, c4 - c3);  // requant 0
+      // ---- conv1 + requant 1 + store, G column blocks at a time ----
+      unsigned char *tile_dst = reinterpret_cast<unsigned char *>(a.dst) + obase * row_bytes;
+      for (int cg = 0; cg < NCG; ++cg) {
+        const int chb = 32 * G * cg + lch;  // this lane's first channel in the group
+        v16i acc1[G];
+        float cp[G], bs[G], sc[G];
+#pragma unroll
         for (int cc = 0; cc < G; ++cc) {
-          const v4i w = *reinterpret_cast<const v4i *>(
-              w1s + ((cg * G + cc) * OCB + r) * 1024 + lane16);
-          acc1[cc] = mfma_i8(mid[r], w, acc1[cc]);
+          acc1[cc] = zero16;
+          cp[cc] = comp1[chb + cc];
+          bs[cc] = bias1[chb + cc];
+          sc[cc] = scale1[chb + cc];
         }
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int pl = 8 * (e >> 2) + 4 * h + (e & 3);  // pixel (MFMA row) of register e
-        if (pl < nvalid) {
-          float f[G];
+        for (int r = 0; r < OCB; ++r)
 #pragma unroll
-          for (int cc = 0; cc < G; ++cc) f[cc] = requant(acc1[cc][e], bs[cc], sc[cc], relu1);
-          store_group<DST, G>(a.dst, (obase + pl) * OC1 + chb, f, a.rm1);
-        }
+          for (int cc = 0; cc < G; ++cc) {
+            const v4i w = *reinterpret_cast<const v4i *>(
+                w1s + ((cg * G + cc) * OCB + r) * 1024 + lane16);
+            acc1[cc] = mfma_i8(mid[r], w, acc1[cc]);
+          }
+        // register e of the accumulator = pixel 8*(e>>2) + 4h + (e&3) of the tile
+        const unsigned lane_off = (unsigned)h4 * row_bytes + (unsigned)chb * ESZ;
+        auto emit = [&](auto fast_tag, auto check_tag) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int pl = 8 * (e >> 2) + (e & 3);  // + 4h, folded into lane_off
+            if (!decltype(check_tag)::value || pl + 4 * h < nvalid) {
+              int v[G];
+#pragma unroll
+              for (int cc = 0; cc < G; ++cc) v[cc] = acc1[cc][e];
+              store_group<DST, G, decltype(fast_tag)::value>(
+                  tile_dst + (size_t)(lane_off + (unsigned)pl * row_bytes), v, cp, bs, sc, relu1, a.rm1);
+            }
+          }
+        };
+        using T = std::true_type;
+        using F = std::false_type;
+        if (fast) { if (nvalid == 32) emit(T{}, F{}); else emit(T{}, T{}); }
+        else      { if (nvalid == 32) emit(F{}, F{}); else emit(F{}, T{}); }
       }
+      DFX_STAMP(c5);
+      DFX_ACC(3, c5 - c4);  // conv1 + requant 1 + stores
+      DFX_ACC(6, 1);
     }
+    DFX_STAMP(c6);
+    __syncthreads();  // (B) every compute wave is done reading this unit's halo tile
+    DFX_STAMP(c7);
+    DFX_ACC(4, c7 - c6);  // wait at barrier B
+    DFX_ACC(5, c7 - c0);  // whole unit
+    DFX_ACC(7, 1);
+    unit = next;
   }
+#ifdef DFX_STAMPS
+  if (lane == 0)
+    for (int k = 0; k < 8; ++k) g.prof[((size_t)blockIdx.x * 8 + wave) * 8 + k] = prof_acc[k];
+#endif
 }
 
 }  // namespace dfx

@@ -13,6 +13,8 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -62,7 +64,8 @@ struct dfx_conv {
   MfmaGeom geom;
   int icb, ocb, G, grid, block, lds;
   void *d_wei, *d_wei1, *d_consts;
-  size_t wei_bytes, wei1_bytes, consts_count;
+  int *d_queue;  // MFMA variant: {next unit, finished workgroups}
+  unsigned long long *d_prof;  // DFX_STAMPS builds only
   bool weights_set;
   void *d_src, *d_dst;  // lazily allocated for dfx_conv_submit_host
   hipStream_t host_stream;
@@ -201,37 +204,55 @@ static int validate_conv(const dfx_conv_desc &d) {
 
 static size_t round16(size_t v) { return (v + 15) & ~(size_t)15; }
 
-// pick the unit decomposition of the MFMA variant; false if nothing fits LDS
+// Pick the unit decomposition of the MFMA variant: TH output rows x TW output
+// columns per unit, either full-width rows (linear pixel numbering) or TW a
+// multiple of 32.  Scored by how well a unit's 32-pixel tiles fill the 7 compute
+// waves, how little halo it re-reads, and whether the loader wave can hold the
+// whole halo tile in registers.  false if nothing fits LDS.
 static bool pick_geometry(const dfx_conv_desc &d, MfmaGeom &g, int &lds) {
   const int ICB = d.ic / 32, OCB = d.oc / 32, NCB = d.oc1x1 / 32;
   const size_t fixed = (size_t)OCB * 9 * ICB * 1024 + (size_t)NCB * OCB * 1024 +
-                       round16((size_t)3 * (d.oc + d.oc1x1) * 4);
+                       round16((size_t)3 * (d.oc + d.oc1x1) * 4 + 16);
   const size_t budgets[2] = {81920, 163840};  // two / one workgroup(s) per CU
   // rows per unit wanted for parallelism: aim for >= ~1024 units
   int th_par = (int)(((long long)d.bs * d.oh) / 1024);
   if (th_par < 1) th_par = 1;
   if (th_par < 2 && (long long)d.bs * d.oh / 2 >= 256) th_par = 2;
+  if (th_par > 16) th_par = 16;
   for (size_t budget : budgets) {
     if (fixed >= budget) continue;
-    auto th_fit = [&](int tw) {
-      const size_t row = (size_t)(tw + 2) * d.ic;
-      long long t = (long long)((budget - fixed) / row) - 2;
-      return (int)(t > d.oh ? d.oh : t);
-    };
-    int th = th_fit(d.ow);  // mode A: full-width rows, linear pixel numbering
-    int tw = d.ow, linear = 1;
-    if (th < 2 && d.ow > 32) {  // mode B: split wide rows into 32-multiples
-      int tw_b = d.ow >= 128 ? 128 : (d.ow / 32) * 32;
-      int th_b = th_fit(tw_b);
-      if (th_b > th) { th = th_b; tw = tw_b; linear = 0; }
-    }
-    if (th < 1) continue;
-    if (th > th_par) th = th_par;
-    if (th > 16) th = 16;
-    g.th = th; g.tw = tw; g.linear = linear;
-    g.uy = (d.oh + th - 1) / th;
-    g.ux = (d.ow + tw - 1) / tw;
-    lds = (int)(fixed + (size_t)(th + 2) * (tw + 2) * d.ic);
+    double best = -1.0;
+    for (int mode = 0; mode < 2; ++mode)
+      for (int tw = (mode == 0 ? d.ow : 32); tw <= (mode == 0 ? d.ow : std::min(d.ow, 256)); tw += 32) {
+        if (mode == 1 && tw >= d.ow) break;  // full width is mode 0
+        for (int th = 1; th <= std::min(d.oh, th_par); ++th) {
+          const size_t tile = (size_t)(th + 2) * (tw + 2) * d.ic + 16;  // +16: the loader's dump slot
+          if (fixed + tile > budget) break;
+          const int npx = th * tw;
+          const int ntiles = mode == 0 ? (npx + 31) / 32 : th * (tw / 32);
+          const int rounds = (ntiles + MFMA_CW - 1) / MFMA_CW;
+          const double px_eff = (double)npx / (32.0 * ntiles);
+          const double wave_eff = (double)ntiles / (MFMA_CW * rounds);
+          const double halo_eff = (double)npx / ((th + 2.0) * (tw + 2.0));
+          // edge units are partial: fraction of the covered area that is real output
+          const double cover = ((double)d.oh * d.ow) /
+                               ((double)((d.oh + th - 1) / th * th) * ((d.ow + tw - 1) / tw * tw));
+          const bool oversize = (tile - 16) / 16 > (size_t)64 * MFMA_LC;
+          const double score = px_eff * wave_eff * cover * (0.75 + 0.25 * halo_eff) * (oversize ? 0.9 : 1.0);
+          if (score > best) {
+            best = score;
+            g.th = th; g.tw = tw; g.linear = mode == 0;
+          }
+        }
+      }
+    if (best < 0) continue;
+    g.uy = (d.oh + g.th - 1) / g.th;
+    g.ux = (d.ow + g.tw - 1) / g.tw;
+    g.total_units = d.bs * g.uy * g.ux;
+    g.row_chunks = (g.tw + 2) * (d.ic / 16);
+    g.tile_chunks = (g.th + 2) * g.row_chunks;
+    g.row_magic = (unsigned)(((1ull << 32) + g.row_chunks - 1) / g.row_chunks);
+    lds = (int)(fixed + (size_t)g.tile_chunks * 16 + 16);
     return true;
   }
   return false;
@@ -286,8 +307,33 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     h->icb = d.ic / 32; h->ocb = d.oc / 32;
     const int ncb = d.oc1x1 / 32;
     h->G = (ncb % 4 == 0) ? 4 : (ncb % 2 == 0 ? 2 : 1);
-    h->grid = d.bs * h->geom.uy * h->geom.ux;
+    {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        delete h;
+        return fail(DFX_ERR_HIP, "conv_create: cannot query the device");
+      }
+      const int per_cu = h->lds <= 81920 ? 2 : 1;  // persistent workgroups resident per CU
+      h->grid = prop.multiProcessorCount * per_cu;
+      if (h->grid > h->geom.total_units) h->grid = h->geom.total_units;
+    }
     h->block = MFMA_THREADS;
+    if (hipMalloc((void **)&h->d_queue, 16) != hipSuccess ||
+        hipMemset(h->d_queue, 0, 16) != hipSuccess) {
+      delete h;
+      return fail(DFX_ERR_HIP, "conv_create: cannot allocate the unit queue");
+    }
+    h->geom.queue = h->d_queue;
+    h->geom.fast = 0;
+#ifdef DFX_STAMPS
+    if (hipMalloc((void **)&h->d_prof, (size_t)h->grid * 64 * 8) != hipSuccess ||
+        hipMemset(h->d_prof, 0, (size_t)h->grid * 64 * 8) != hipSuccess) {
+      delete h;
+      return fail(DFX_ERR_HIP, "conv_create: cannot allocate the stamp buffer");
+    }
+    h->geom.prof = h->d_prof;
+#endif
     a.rows_per_unit = h->geom.th;
     a.units_per_image = h->geom.uy * h->geom.ux;
     snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_mfma_fused_kernel<%d,%d,%d,%d>", h->icb,
@@ -330,9 +376,9 @@ int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei, const void *bia0, con
   const size_t nw0 = (size_t)OC * IC * d.kh * d.kw, nw1 = (size_t)OC1 * OC;
   std::vector<int8_t> p0(nw0), p1(nw1 ? nw1 : 1);
   std::vector<float> cst((size_t)3 * (OC + OC1), 0.0f);
-  int32_t *comp0 = reinterpret_cast<int32_t *>(cst.data());
+  float *comp0 = cst.data();  // f32: exact, |comp| < 2^24 for K <= 1023
   float *b0 = cst.data() + OC, *s0 = cst.data() + 2 * OC;
-  int32_t *comp1 = reinterpret_cast<int32_t *>(cst.data() + 3 * OC);
+  float *comp1 = cst.data() + 3 * OC;
   float *b1 = cst.data() + 3 * OC + OC1, *s1 = cst.data() + 3 * OC + 2 * OC1;
   for (int c = 0; c < OC; ++c) {
     b0[c] = d.bia0_dt == DFX_UNDEF ? 0.0f : bias_to_f32(bia0, d.bia0_dt, c);
@@ -373,29 +419,68 @@ int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei, const void *bia0, con
       int32_t s = 0;
       for (int ic = 0; ic < IC; ++ic)
         for (int tap = 0; tap < 9; ++tap) s += wei[dfx_blocked_offset(oc, ic, tap / 3, tap % 3, IC, 3, 3)];
-      comp0[oc] = 128 * s;
+      comp0[oc] = (float)(128 * s);
     }
     for (int o1 = 0; o1 < OC1; ++o1) {
       int32_t s = 0;
       for (int oc = 0; oc < OC; ++oc) s += wei1[dfx_blocked_offset(o1, oc, 0, 0, OC, 1, 1)];
-      comp1[o1] = 128 * s;
+      comp1[o1] = (float)(128 * s);
     }
+    // Fast requant path: both stages round to nearest-even and, from the weights
+    // themselves, no value can be NaN or reach +-2^31 before vcvtps2dq, so the x86
+    // overflow/NaN selects can never fire.  |acc| <= 255 * max(sum w+, -sum w-).
+    bool fast = d.conv0_round_mode == DFX_ROUND_NEAREST && d.conv1_round_mode == DFX_ROUND_NEAREST;
+    auto bounded = [](double amax, float bias, float scale) {
+      if (!std::isfinite(bias) || !std::isfinite(scale)) return false;
+      return (amax + std::fabs((double)bias)) * std::fabs((double)scale) * 1.0001 + 2.0 < 2147480000.0;
+    };
+    for (int oc = 0; oc < OC && fast; ++oc) {
+      double pos = 0, neg = 0;
+      for (int ic = 0; ic < IC; ++ic)
+        for (int tap = 0; tap < 9; ++tap) {
+          const int w = wei[dfx_blocked_offset(oc, ic, tap / 3, tap % 3, IC, 3, 3)];
+          (w > 0 ? pos : neg) += w;
+        }
+      fast = bounded(255.0 * std::max(pos, -neg), b0[oc], s0[oc]);
+    }
+    for (int o1 = 0; o1 < OC1 && fast; ++o1) {
+      double pos = 0, neg = 0;
+      for (int oc = 0; oc < OC; ++oc) {
+        const int w = wei1[dfx_blocked_offset(o1, oc, 0, 0, OC, 1, 1)];
+        (w > 0 ? pos : neg) += w;
+      }
+      fast = bounded(255.0 * std::max(pos, -neg), b1[o1], s1[o1]);
+    }
+    h->geom.fast = fast ? 1 : 0;
   } else {
     memcpy(p0.data(), wei, nw0);
     if (fused) memcpy(p1.data(), wei1, nw1);
   }
 
-  if (!h->d_wei) {
-    HIP_TRY(hipMalloc(&h->d_wei, nw0));
-    HIP_TRY(hipMalloc(&h->d_wei1, nw1 ? nw1 : 16));
-    HIP_TRY(hipMalloc(&h->d_consts, cst.size() * 4));
+  if (h->variant == DFX_VARIANT_MFMA_FUSED) {
+    // one buffer in LDS-image order: [W0 fragments | W1 fragments | constants]
+    const size_t cbytes = round16(cst.size() * 4);
+    if (!h->d_wei) HIP_TRY(hipMalloc(&h->d_wei, nw0 + nw1 + cbytes));
+    char *base = (char *)h->d_wei;
+    HIP_TRY(hipMemcpy(base, p0.data(), nw0, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base + nw0, p1.data(), nw1, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base + nw0 + nw1, cst.data(), cst.size() * 4, hipMemcpyHostToDevice));
+    h->args.wei = (const int8_t *)base;
+    h->args.wei1 = (const int8_t *)(base + nw0);
+    h->args.consts = (const float *)(base + nw0 + nw1);
+  } else {
+    if (!h->d_wei) {
+      HIP_TRY(hipMalloc(&h->d_wei, nw0));
+      HIP_TRY(hipMalloc(&h->d_wei1, nw1 ? nw1 : 16));
+      HIP_TRY(hipMalloc(&h->d_consts, cst.size() * 4));
+    }
+    HIP_TRY(hipMemcpy(h->d_wei, p0.data(), nw0, hipMemcpyHostToDevice));
+    if (nw1) HIP_TRY(hipMemcpy(h->d_wei1, p1.data(), nw1, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->d_consts, cst.data(), cst.size() * 4, hipMemcpyHostToDevice));
+    h->args.wei = (const int8_t *)h->d_wei;
+    h->args.wei1 = (const int8_t *)h->d_wei1;
+    h->args.consts = (const float *)h->d_consts;
   }
-  HIP_TRY(hipMemcpy(h->d_wei, p0.data(), nw0, hipMemcpyHostToDevice));
-  if (nw1) HIP_TRY(hipMemcpy(h->d_wei1, p1.data(), nw1, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(h->d_consts, cst.data(), cst.size() * 4, hipMemcpyHostToDevice));
-  h->args.wei = (const int8_t *)h->d_wei;
-  h->args.wei1 = (const int8_t *)h->d_wei1;
-  h->args.consts = (const float *)h->d_consts;
   h->weights_set = true;
   return DFX_OK;
 }
@@ -452,11 +537,22 @@ int dfx_conv_query(const dfx_conv_t *h, dfx_conv_info *info) {
   return DFX_OK;
 }
 
+#ifdef DFX_STAMPS
+// diagnostic build only: copies the [grid][8 waves][8] stamp sums of the last launch
+int dfx_debug_read_stamps(dfx_conv_t *h, unsigned long long *out, int max_entries) {
+  if (!h || !h->d_prof) return fail(DFX_ERR_STATE, "no stamps");
+  int n = h->grid * 64;
+  if (n > max_entries) n = max_entries;
+  HIP_TRY(hipMemcpy(out, h->d_prof, (size_t)n * 8, hipMemcpyDeviceToHost));
+  return n;
+}
+#endif
+
 int dfx_conv_destroy(dfx_conv_t *h) {
   if (!h) return DFX_OK;
   if (h->host_stream) (void)hipStreamDestroy(h->host_stream);
   (void)hipFree(h->d_wei); (void)hipFree(h->d_wei1); (void)hipFree(h->d_consts);
-  (void)hipFree(h->d_src); (void)hipFree(h->d_dst);
+  (void)hipFree(h->d_src); (void)hipFree(h->d_dst); (void)hipFree(h->d_queue);
   delete h;
   return DFX_OK;
 }

@@ -63,8 +63,8 @@ __device__ __forceinline__ int dot4_u8s8(unsigned a, int w) {
 
 // Kernel arguments common to both conv variants.  `consts` holds, as f32/s32
 // arrays in natural channel order: comp0[oc] bias0[oc] scale0[oc] comp1[oc1]
-// bias1[oc1] scale1[oc1]  (comp* = 128 * sum of the channel's weights, used by
-// the MFMA variant's u8 -> s8 offset trick; zero for the generic variant).
+// bias1[oc1] scale1[oc1]  (comp* = 128 * sum of the channel's weights as an exact
+// f32, used by the MFMA variant's u8 -> s8 offset trick; zero for the generic variant).
 struct ConvArgs {
   const uint8_t *src;
   void *dst;

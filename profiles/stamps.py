@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Diagnostic only: runs the DFX_STAMPS build (libdfx_hip_stamps.so: in-kernel
+s_memtime stamps) on a bench workload and prints where a workgroup's cycles go.
+Never quote this build's run time; read its shares."""
+import ctypes
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+capi = importlib.import_module("deep-fusion_amd.capi")
+capi._LIB = os.path.join(ROOT, "deep-fusion_amd", "libdfx_hip_stamps.so")
+import torch  # noqa: E402
+import cases as C  # noqa: E402
+import hipref  # noqa: E402
+from dataclasses import replace  # noqa: E402
+
+dst = {"u8": C.U8, "s32": C.S32, "f32": C.F32, "s8": C.S8}[sys.argv[1] if len(sys.argv) > 1 else "u8"]
+case = C.ConvCase("res2a", 128, 64, 56, 56, 64, 256, dst_dt=dst)
+data = C.generate(case)
+op = hipref.make_conv(case, data)
+info = op.info()
+src = torch.from_numpy(data["src"]).cuda()
+tdt = {C.F32: torch.float32, C.S32: torch.int32, C.S8: torch.int8, C.U8: torch.uint8}[dst]
+out = torch.empty(op.dst_shape, dtype=tdt, device="cuda")
+for _ in range(3):
+    op.submit(src, out)
+torch.cuda.synchronize()
+L = capi.lib()
+L.dfx_debug_read_stamps.restype = ctypes.c_int
+L.dfx_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+buf = np.zeros(info.grid * 64, dtype=np.uint64)
+# the kernel overwrites (not accumulates across launches): values are of the last launch
+n = L.dfx_debug_read_stamps(op._h, buf.ctypes.data_as(ctypes.c_void_p), buf.size)
+p = buf[:n].reshape(info.grid, 8, 8).astype(np.float64)
+comp, load = p[:, :7, :], p[:, 7, :]
+print("kernel", info.kernel_name.decode(), "grid", info.grid, "rows/unit", info.rows_per_unit)
+units = comp[:, :, 7].mean()
+print("units per workgroup (mean): %.2f, tiles per compute wave: %.2f" % (units, comp[:, :, 6].mean()))
+names = ["wait barrier A", "conv0 MFMA", "requant0", "conv1+requant1+stores", "wait barrier B", "whole unit"]
+tot = comp[:, :, 5].sum()
+for k, nm in enumerate(names):
+    print("compute waves  %-24s %10.0f cycles/unit/wave  %5.1f%%" % (nm, comp[:, :, k].sum() / comp[:, :, 7].sum(),
+                                                                  100 * comp[:, :, k].sum() / tot))
+print("compute waves  per tile: conv0 %.0f  requant0 %.0f  conv1+epi %.0f" % tuple(
+    comp[:, :, k].sum() / comp[:, :, 6].sum() for k in (1, 2, 3)))
+names = ["LDS write (+load wait)", "queue atomic", "barrier A", "issue prefetch", "barrier B (= compute)"]
+for k, nm in enumerate(names):
+    print("loader wave    %-24s %10.0f cycles/unit" % (nm, load[:, k].sum() / load[:, 7].sum()))

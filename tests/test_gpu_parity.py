@@ -189,3 +189,24 @@ def test_concat_gathered(hip, oracle):
     op.submit_gathered(g, offs, dst)
     torch.cuda.synchronize()
     hip.assert_bit_equal(dst.cpu().numpy(), oracle.concat(shards, True), "gathered")
+
+
+def test_repeated_submits_rearm_queue(hip, oracle):
+    """The persistent MFMA kernel pulls units from a device-side queue that the last
+    workgroup re-arms; back-to-back submits of one op must all be complete and equal."""
+    import torch
+    for case in (replace(C.CONFIG3_SMALL, bs=5), C.CONFIG2, C.ConvCase("w96", 3, 64, 6, 96, 64, 128, dst_dt=C.S32)):
+        data = C.generate(case)
+        ref = hip.oracle_conv(oracle, case, data)
+        op = hip.make_conv(case, data)
+        src = torch.from_numpy(data["src"]).cuda()
+        tdt = {C.F32: torch.float32, C.S32: torch.int32, C.S8: torch.int8, C.U8: torch.uint8}[case.dst_dt]
+        outs = [torch.empty(op.dst_shape, dtype=tdt, device="cuda") for _ in range(6)]
+        for o in outs:
+            o.view(torch.uint8).fill_(0xCD)
+        for o in outs:
+            op.submit(src, o)
+        torch.cuda.synchronize()
+        for o in outs:
+            hip.assert_bit_equal(o.cpu().numpy(), ref, "repeat " + case.name)
+        op.close()
