@@ -8,7 +8,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-_LIB = os.path.join(_PKG, "libdfx_hip.so")
+_LIB = os.environ.get("DFX_LIB_PATH") or os.path.join(_PKG, "libdfx_hip.so")  # override: debugging only
 _HEADER = os.path.join(_ROOT, "include", "dfx.h")
 
 DFX_UNDEF, DFX_F32, DFX_S32, DFX_S8, DFX_U8 = 0, 1, 2, 3, 4

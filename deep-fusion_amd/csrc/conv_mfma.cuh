@@ -7,18 +7,21 @@
 //   infer_conv0conv1                   src/op_conv.cc:140-260
 //
 // Structure
-//  * PERSISTENT workgroups of 8 waves, two per CU (4 waves per SIMD, <= 128
-//    VGPRs: a single wave issues at most one VALU instruction every ~4-5 cycles,
-//    so the requant epilogue needs the occupancy).  The 3x3 and 1x1 weights,
-//    already packed in MFMA fragment order by the host, are copied to LDS ONCE
-//    per workgroup; the workgroup then pulls "units" (TH output rows x TW output
-//    columns of one image) from a device-side queue (one atomicAdd per unit, the
-//    balance211 of op_conv.cc:155-156 made dynamic).
-//  * Wave roles: waves 0..6 compute (each walks 32-pixel tiles of the unit);
-//    wave 7 is the LOADER: while the compute waves work on unit k it holds the
-//    whole input halo tile of unit k+1 in its own registers (global loads issued
-//    early), and writes it (xor 0x80, swizzled) to LDS between the two barriers
-//    that separate units.  Compute waves never wait on a global load.
+//  * ONE PERSISTENT WORKGROUP PER CU: 16 waves (4 per SIMD, <= 128 VGPRs: a single
+//    wave issues at most one VALU instruction every ~4-5 cycles, so the requant
+//    epilogue needs the occupancy).  The 3x3 and 1x1 weights, packed in MFMA
+//    fragment order by the host, are copied to LDS ONCE per CU.
+//  * The 16 waves form two independent TEAMS of 7 compute waves + 1 loader wave.
+//    A team works on "units" (TH output rows x TW output columns of one image)
+//    drawn from a device-side queue (one atomicAdd per unit: the balance211 of
+//    op_conv.cc:155-156 made dynamic).  Each team owns TWO input-tile buffers in
+//    LDS.  The loader holds the whole halo tile of the next unit in its registers
+//    (global loads issued early), writes it (xor 0x80, swizzled) into the free
+//    buffer and publishes it with an LDS flag; compute waves consume a buffer and
+//    count themselves off on an LDS counter.  There is no workgroup barrier after
+//    start-up: compute waves never wait for a global load, for the loader's LDS
+//    write, or for each other, so the MFMA, VALU and store phases of different
+//    waves interleave instead of running in lock step.
 //  * conv0 is D0[oc][px] = sum_k W0[oc][k] * X[k][px] with
 //    v_mfma_i32_32x32x32_i8: packed s8 weights are the A operand (rows = oc),
 //    input pixels the B operand (columns = px).  One MFMA eats 32 input channels
@@ -62,8 +65,10 @@
 
 namespace dfx {
 
-constexpr int MFMA_THREADS = 512;  // 8 waves: 7 compute + 1 loader
-constexpr int MFMA_CW = 7;         // compute waves
+constexpr int MFMA_THREADS = 1024;  // 16 waves = 2 teams x (7 compute + 1 loader)
+constexpr int MFMA_TEAMS = 2;
+constexpr int MFMA_CW = 7;          // compute waves per team
+constexpr int MFMA_CTRL_BYTES = 64; // LDS control block: per team full[2], done[2], unit[2]
 constexpr int MFMA_LC = 22;        // 16-byte chunks the loader wave holds per lane (88 VGPRs)
 
 __device__ __forceinline__ v16i mfma_i8(v4i a, v4i b, v16i c) {
@@ -87,9 +92,11 @@ struct MfmaGeom {  // unit decomposition chosen by the host (dfx_api.hip)
   int tile_chunks;  // (th + 2) * row_chunks
   unsigned row_magic;  // ceil(2^32 / row_chunks): q / row_chunks == umulhi(q, row_magic)
   int fast;            // 1: requant fast path is valid (see header comment)
-  int *queue;          // [0] next unit, [1] finished workgroups; both 0 between launches
+  int tile_stride;     // bytes between the 2 x MFMA_TEAMS input-tile buffers in LDS
+  int static_rounds;   // units a team owns statically before it turns to the queue
+  int *queue;          // [0] next unit, [1] finished loaders; both 0 between launches
 #ifdef DFX_STAMPS
-  unsigned long long *prof;  // diagnostic build only: [workgroup][wave][8] cycle sums
+  unsigned long long *prof;  // diagnostic build only: [workgroup][wave][16] cycle sums
 #endif
 };
 
@@ -115,17 +122,37 @@ __device__ __forceinline__ float acc_to_f32(int raw, float comp, float bias) {
   return __fadd_rn(__fadd_rn(__int2float_rn(raw), comp), bias);
 }
 
-// ---- one pixel's G consecutive channels -> one store.  FAST: RNE, all values
-// finite and |f| < 2^31 (host-proven), so the x86 overflow/NaN selects are dead
-// and u8 output can use v_cvt_pk_u8_f32 (RNE + [0,255] saturation, probed on
-// gfx950: tools/probe/probe_valu.hip), which also subsumes the ReLU. ----
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// ---- one pixel's G consecutive channels -> one store.
+// FAST (host-proven preconditions, dfx_api.hip): both stages round to nearest-even;
+// every value is finite and |f| < 2^31, so the x86 overflow/NaN selects are dead;
+// comp + bias is an exact integer-valued f32 and |acc + bias| < 2^24, so the single
+// add of cb = comp + bias equals the reference's float(acc) + float(bias) bit for
+// bit.  u8 output then uses v_cvt_pk_u8_f32 (RNE + [0,255] saturation, probed on
+// gfx950: tools/probe/probe_valu.hip), which also subsumes the ReLU.
+// EXACT: everything else (any round mode, x86 overflow/NaN semantics, two adds). ----
 template <int DST, int G, bool FAST>
 __device__ __forceinline__ void store_group(unsigned char *p, const int (&acc)[G],
                                             const float (&cp)[G], const float (&bs)[G],
                                             const float (&sc)[G], bool relu, int rm) {
   float f[G];
+  if (FAST) {  // bs holds comp + bias; packed f32 math where G allows (v_pk_add/mul_f32)
+    if (G >= 2) {
 #pragma unroll
-  for (int c = 0; c < G; ++c) f[c] = __fmul_rn(acc_to_f32(acc[c], cp[c], bs[c]), sc[c]);
+      for (int c = 0; c < G; c += 2) {
+        v2f x = {__int2float_rn(acc[c]), __int2float_rn(acc[c + 1])};
+        x = (x + v2f{bs[c], bs[c + 1]}) * v2f{sc[c], sc[c + 1]};
+        f[c] = x[0];
+        f[c + 1] = x[1];
+      }
+    } else {
+      f[0] = __fmul_rn(__fadd_rn(__int2float_rn(acc[0]), bs[0]), sc[0]);
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < G; ++c) f[c] = __fmul_rn(acc_to_f32(acc[c], cp[c], bs[c]), sc[c]);
+  }
   if (DST == DFX_F32) {
 #pragma unroll
     for (int c = 0; c < G; ++c) f[c] = relu ? relu_x86(f[c]) : f[c];
@@ -167,50 +194,59 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
   constexpr int ESZ = (DST == DFX_F32 || DST == DFX_S32) ? 4 : 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
+  DFX_STAMP(t_entry);
   const int OC1 = a.oc1, NCB = OC1 >> 5, NCG = NCB / G;
   unsigned char *w0s = smem;                                   // [OCB][9][ICB][64 lanes][16 B]
   unsigned char *w1s = w0s + OCB * 9 * ICB * 1024;             // [NCB][OCB][64 lanes][16 B]
   float *cst = reinterpret_cast<float *>(w1s + NCB * OCB * 1024);
-  const int cst_bytes = (3 * (OC + OC1) * 4 + 16 + 15) & ~15;  // +16: the queue slot
-  int *sh_next = reinterpret_cast<int *>(cst + 3 * (OC + OC1));
-  unsigned char *ins = reinterpret_cast<unsigned char *>(cst) + cst_bytes;  // halo tile
+  const int cst_bytes = (3 * (OC + OC1) * 4 + 15) & ~15;
+  int *ctrl = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(cst) + cst_bytes);
+  unsigned char *tiles = reinterpret_cast<unsigned char *>(ctrl) + MFMA_CTRL_BYTES;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
+  const int team = wave >> 3, cw = wave & 7;                  // cw == MFMA_CW: the team's loader
   const int LW = g.tw + 2;
   const int upi = g.uy * g.ux;
+  // per-team control words (LDS): full[b] = number of tiles published into buffer b,
+  // done[b] = number of compute-wave completions on buffer b, unit[b] = unit id or -1
+  int *full = ctrl + team * 6, *done = full + 2, *unit_of = full + 4;
+  unsigned char *team_tiles = tiles + (size_t)team * 2 * g.tile_stride;
 
   // ---- weights + constants: the host keeps them in ONE device buffer laid out
   //      exactly like the LDS image [W0 fragments | W1 fragments | constants], so a
   //      single linear copy stages them.  All global loads of a pass are issued
-  //      before the first LDS write: one memory round trip per 64 KB. ----
-  auto stage_weights = [&]() {
+  //      before the first LDS write: one memory round trip per 128 KB. ----
+  auto stage_weights = [&]() {  // called by the 14 compute waves (the loaders hold tile data)
+    constexpr int NT = MFMA_TEAMS * MFMA_CW * 64;
+    const int ctid = (team * MFMA_CW + cw) * 64 + lane;
     const v4i *s = reinterpret_cast<const v4i *>(a.wei);
     v4i *d = reinterpret_cast<v4i *>(smem);
     const int total = OCB * 9 * ICB * 64 + NCB * OCB * 64 + (3 * (OC + OC1) * 4 + 15) / 16;
-    for (int base = 0; base < total; base += 8 * MFMA_THREADS) {
-      const int q0 = base + tid, last = total - 1;
-      const v4i t0 = s[min(q0 + 0 * MFMA_THREADS, last)];
-      const v4i t1 = s[min(q0 + 1 * MFMA_THREADS, last)];
-      const v4i t2 = s[min(q0 + 2 * MFMA_THREADS, last)];
-      const v4i t3 = s[min(q0 + 3 * MFMA_THREADS, last)];
-      const v4i t4 = s[min(q0 + 4 * MFMA_THREADS, last)];
-      const v4i t5 = s[min(q0 + 5 * MFMA_THREADS, last)];
-      const v4i t6 = s[min(q0 + 6 * MFMA_THREADS, last)];
-      const v4i t7 = s[min(q0 + 7 * MFMA_THREADS, last)];
-      d[min(q0 + 0 * MFMA_THREADS, last)] = t0;
-      d[min(q0 + 1 * MFMA_THREADS, last)] = t1;
-      d[min(q0 + 2 * MFMA_THREADS, last)] = t2;
-      d[min(q0 + 3 * MFMA_THREADS, last)] = t3;
-      d[min(q0 + 4 * MFMA_THREADS, last)] = t4;
-      d[min(q0 + 5 * MFMA_THREADS, last)] = t5;
-      d[min(q0 + 6 * MFMA_THREADS, last)] = t6;
-      d[min(q0 + 7 * MFMA_THREADS, last)] = t7;
+    for (int base = 0; base < total; base += 8 * NT) {
+      const int q0 = base + ctid, last = total - 1;
+      const v4i t0 = s[min(q0 + 0 * NT, last)];
+      const v4i t1 = s[min(q0 + 1 * NT, last)];
+      const v4i t2 = s[min(q0 + 2 * NT, last)];
+      const v4i t3 = s[min(q0 + 3 * NT, last)];
+      const v4i t4 = s[min(q0 + 4 * NT, last)];
+      const v4i t5 = s[min(q0 + 5 * NT, last)];
+      const v4i t6 = s[min(q0 + 6 * NT, last)];
+      const v4i t7 = s[min(q0 + 7 * NT, last)];
+      d[min(q0 + 0 * NT, last)] = t0;
+      d[min(q0 + 1 * NT, last)] = t1;
+      d[min(q0 + 2 * NT, last)] = t2;
+      d[min(q0 + 3 * NT, last)] = t3;
+      d[min(q0 + 4 * NT, last)] = t4;
+      d[min(q0 + 5 * NT, last)] = t5;
+      d[min(q0 + 6 * NT, last)] = t6;
+      d[min(q0 + 7 * NT, last)] = t7;
     }
+    if (ctid < MFMA_CTRL_BYTES / 4) ctrl[ctid] = 0;
   };
 
-  if (wave == MFMA_CW) {
+  if (cw == MFMA_CW) {
     // =========================== loader wave ===========================
     const v4i x80 = v4i{(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
     v4i pf[MFMA_LC];
@@ -252,69 +288,76 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
     _Pragma("unroll") for (int i = 0; i < MFMA_LC; ++i) pf[i] =                         \
         load_chunk(src_n_, y0_, x0_, lq_ + 64 * i);                                     \
   } while (0)
-#ifdef DFX_STAMPS
-    unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    // Everything between barrier (B) of unit k and barrier (A) of unit k+1 is on
-    // the workgroup's critical path, so it is only the LDS writes themselves: the
-    // destination offsets are precomputed here, and the queue index is drawn one
-    // unit ahead (the device-scope atomic takes microseconds to return).
+    // Unit sequence of this team: the first `static_rounds` units are owned
+    // statically (round j -> unit j*T + team id; no atomic: 2 x gridDim loaders
+    // hammering one queue word at kernel start cost ~12 us), the rest come from the
+    // device-side queue.  Draws are device-scope atomics that take microseconds to
+    // return: one is kept in flight and only broadcast (readfirstlane = wait) when needed.
+    const int T = (int)gridDim.x * MFMA_TEAMS, tg = (int)blockIdx.x * MFMA_TEAMS + team;
+    auto unit_at = [&](int j) {
+      int v = j * T + tg;
+      if (j >= g.static_rounds) {
+        v = 0x7fffffff;
+        if (lane == 0) v = g.static_rounds * T + atomicAdd(g.queue, 1);
+      }
+      return v;
+    };
+
     int wr_off[MFMA_LC];
 #pragma unroll
     for (int i = 0; i < MFMA_LC; ++i) wr_off[i] = chunk_lds_off(lane + 64 * i);
-    int unit = blockIdx.x;
-    int nxt = 0;
-    if (lane == 0) nxt = (int)gridDim.x + atomicAdd(g.queue, 1);
-    if (unit < g.total_units) DFX_PREFETCH(unit);  // first tile's loads fly during the weight copy
-    stage_weights();
-    while (unit < g.total_units) {
-      DFX_STAMP(l0);
+    int cur = __builtin_amdgcn_readfirstlane(unit_at(0));
+    int nxt_v = unit_at(1);
+    int jn = 2;
+    if (cur < g.total_units) DFX_PREFETCH(cur);  // first tile's loads fly during the weight copy
+    __syncthreads();  // the only workgroup barrier: weights + control block are in LDS
+
+    for (int k = 0;; ++k) {
+      const int b = k & 1;
+      unsigned char *ins = team_tiles + (size_t)b * g.tile_stride;
+      // buffer b is free once the 7 compute waves have finished its previous tile
+      while (__hip_atomic_load(done + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < MFMA_CW * (k >> 1))
+        __builtin_amdgcn_s_sleep(2);
+      const bool valid = cur < g.total_units;
+      if (valid) {
 #pragma unroll
-      for (int i = 0; i < MFMA_LC; ++i)   // write-late half of the staging
-        *reinterpret_cast<v4i *>(ins + wr_off[i]) = pf[i];
-      if (g.tile_chunks > 64 * MFMA_LC) {  // oversized tile: the rest is staged synchronously
-        const uint8_t *src_n; int y0, x0;
-        unit_origin(unit, src_n, y0, x0);
-        for (int q = 64 * MFMA_LC + lane; q < g.tile_chunks; q += 64)
-          *reinterpret_cast<v4i *>(ins + chunk_lds_off(q)) = load_chunk(src_n, y0, x0, q);
+        for (int i = 0; i < MFMA_LC; ++i)   // write-late half of the staging
+          *reinterpret_cast<v4i *>(ins + wr_off[i]) = pf[i];
+        if (g.tile_chunks > 64 * MFMA_LC) {  // oversized tile: the rest is staged synchronously
+          const uint8_t *src_n; int y0, x0;
+          unit_origin(cur, src_n, y0, x0);
+          for (int q = 64 * MFMA_LC + lane; q < g.tile_chunks; q += 64)
+            *reinterpret_cast<v4i *>(ins + chunk_lds_off(q)) = load_chunk(src_n, y0, x0, q);
+        }
       }
-      DFX_STAMP(l1);
-      if (lane == 0) *sh_next = nxt;
-      DFX_STAMP(l2);
-      __syncthreads();  // (A) tile and next-unit index visible to the compute waves
-      DFX_STAMP(l3);
-      const int next = *sh_next;
-      if (lane == 0) nxt = (int)gridDim.x + atomicAdd(g.queue, 1);  // for the unit after next
-      if (next < g.total_units) DFX_PREFETCH(next);
-      DFX_STAMP(l4);
-      __syncthreads();  // (B) compute waves are done reading the tile
-      DFX_STAMP(l5);
-      DFX_ACC(0, l1 - l0);  // LDS write (incl. wait for the prefetch loads)
-      DFX_ACC(1, l2 - l1);  // publish queue index
-      DFX_ACC(2, l3 - l2);  // barrier A
-      DFX_ACC(3, l4 - l3);  // issue prefetch
-      DFX_ACC(4, l5 - l4);  // barrier B = compute time of the unit
-      DFX_ACC(7, 1);
-      unit = next;
+      if (lane == 0) unit_of[b] = valid ? cur : -1;
+      // publish: LDS executes a wave's DS instructions in order; the release makes the
+      // compiler keep them ahead of the flag store and waits for them to complete
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // all lanes' tile writes first
+      if (lane == 0) __hip_atomic_store(full + b, (k >> 1) + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (!valid) break;
+      cur = __builtin_amdgcn_readfirstlane(nxt_v);
+      nxt_v = unit_at(jn++);
+      if (cur < g.total_units) DFX_PREFETCH(cur);
     }
-#ifdef DFX_STAMPS
-    if (lane == 0)
-      for (int k = 0; k < 8; ++k) g.prof[((size_t)blockIdx.x * 8 + wave) * 8 + k] = prof_acc[k];
-#endif
-    // last workgroup out re-arms the queue for the next launch
-    if (lane == 0) {
-      const int done = atomicAdd(g.queue + 1, 1);
-      if (done == (int)gridDim.x - 1) {
+#undef DFX_PREFETCH
+    // last loader out re-arms the queue for the next launch.  The draw still in
+    // flight must have been performed before this loader counts itself out, or it
+    // could land after the reset.
+    const int pending = __builtin_amdgcn_readfirstlane(nxt_v);
+    if (lane == 0 && pending >= 0) {
+      const int fin = atomicAdd(g.queue + 1, 1);
+      if (fin == (int)gridDim.x * MFMA_TEAMS - 1) {
         atomicExch(g.queue, 0);
         atomicExch(g.queue + 1, 0);
       }
     }
-#undef DFX_PREFETCH
     return;
   }
 
   // =========================== compute waves ===========================
   stage_weights();
+  __syncthreads();
   const int l31 = lane & 31, h = lane >> 5;
   const float *comp0 = cst, *bias0 = cst + OC, *scale0 = cst + 2 * OC;
   const float *comp1 = cst + 3 * OC, *bias1 = cst + 3 * OC + OC1, *scale1 = cst + 3 * OC + 2 * OC1;
@@ -326,13 +369,18 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
 #ifdef DFX_STAMPS
   unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-  int unit = blockIdx.x;
-  while (unit < g.total_units) {
+  DFX_STAMP(t_loop);
+  DFX_ACC(4, t_loop - t_entry);  // start-up: weights staging + barrier
+  for (int k = 0;; ++k) {
+    const int b = k & 1;
+    const unsigned char *ins = team_tiles + (size_t)b * g.tile_stride;
     DFX_STAMP(c0);
-    __syncthreads();  // (A)
+    while (__hip_atomic_load(full + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (k >> 1) + 1)
+      __builtin_amdgcn_s_sleep(1);
     DFX_STAMP(c1);
-    DFX_ACC(0, c1 - c0);  // wait at barrier A
-    const int next = *sh_next;
+    DFX_ACC(0, c1 - c0);  // wait for the tile
+    const int unit = __builtin_amdgcn_readfirstlane(unit_of[b]);
+    if (unit < 0) break;
 
     const int n = unit / upi, u = unit - n * upi;
     const int uyi = u / g.ux, uxi = u - uyi * g.ux;
@@ -342,7 +390,7 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
     const int tiles_per_row = (tw + 31) >> 5;
     const int ntiles = g.linear ? (npx + 31) >> 5 : th * tiles_per_row;
 
-    for (int t = wave; t < ntiles; t += MFMA_CW) {
+    for (int t = cw; t < ntiles; t += MFMA_CW) {
       // pixel of this lane (conv0 column) and the tile's output base (wave-uniform)
       int ty, tx, nvalid;
       size_t obase;  // dst pixel index of px_local == 0
@@ -368,50 +416,78 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
 
       DFX_STAMP(c2);
       // ---- conv0: 9 taps x ICB k-steps x OCB row blocks ----
+      // Explicit 4-deep fragment ring: the fragments of k-step s+3 are fetched right
+      // after the MFMAs of step s were issued, into the registers last read by the
+      // MFMAs of step s-1.  An LDS load must never target a register that a just-issued
+      // MFMA still has to read as A/B operand (see the note at the 1x1 stage); here at
+      // least OCB MFMAs separate the two.  sched_barrier keeps hipcc from re-mixing.
       v16i acc0[OCB];
 #pragma unroll
       for (int r = 0; r < OCB; ++r) acc0[r] = zero16;
+      {
+        constexpr int NS = 9 * ICB;  // k-steps
+        v4i fb[4], fw[4][OCB];
+        auto fetch = [&](int st, int slot) {  // st, slot are compile-time after unrolling
+          const int tap = st / ICB, c = st % ICB;
+          const int P = Pb + (tap / 3) * LW + (tap % 3);
+          fb[slot] = *reinterpret_cast<const v4i *>(ins + P * IC + 16 * ((2 * c + h) ^ chunk_swizzle<CP>(P)));
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
+          for (int r = 0; r < OCB; ++r)
+            fw[slot][r] = *reinterpret_cast<const v4i *>(w0s + ((r * 9 + tap) * ICB + c) * 1024 + lane16);
+        };
+        fetch(0, 0);
+        fetch(1, 1);
+        fetch(2, 2);
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int P = Pb + kh * LW + kw;
-          const int sw = chunk_swizzle<CP>(P);
-          const unsigned char *base = ins + P * IC;
+        for (int st = 0; st < NS; ++st) {
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int c = 0; c < ICB; ++c) {
-            const v4i b = *reinterpret_cast<const v4i *>(base + 16 * ((2 * c + h) ^ sw));
-#pragma unroll
-            for (int r = 0; r < OCB; ++r) {
-              const v4i w = *reinterpret_cast<const v4i *>(
-                  w0s + ((r * 9 + kh * 3 + kw) * ICB + c) * 1024 + lane16);
-              acc0[r] = mfma_i8(w, b, acc0[r]);
-            }
-          }
+          for (int r = 0; r < OCB; ++r) acc0[r] = mfma_i8(fw[st & 3][r], fb[st & 3], acc0[r]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (st + 3 < NS) fetch(st + 3, (st + 3) & 3);
         }
+      }
 
       DFX_STAMP(c3);
       DFX_ACC(1, c3 - c2);  // conv0 MFMA issue
       // ---- requant 0 in registers -> A fragments of the 1x1 ----
       v4i mid[OCB];
+      if (fast) {  // cb0 = comp0 + bias0 (exact, host-proven); ReLU + RNE + sat + pack in one op
 #pragma unroll
-      for (int r = 0; r < OCB; ++r)
+        for (int r = 0; r < OCB; ++r)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int ch = 32 * r + 8 * q + h4;
-          const v4f cp = *reinterpret_cast<const v4f *>(comp0 + ch);
-          const v4f bs = *reinterpret_cast<const v4f *>(bias0 + ch);
-          const v4f sc = *reinterpret_cast<const v4f *>(scale0 + ch);
-          unsigned pk = 0;
+          for (int q = 0; q < 4; ++q) {
+            const int ch = 32 * r + 8 * q + h4;
+            const v4f bs = *reinterpret_cast<const v4f *>(bias0 + ch);
+            const v4f sc = *reinterpret_cast<const v4f *>(scale0 + ch);
+            unsigned pk = 0;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float f = __fmul_rn(acc_to_f32(acc0[r][4 * q + i], cp[i], bs[i]), sc[i]);
-            if (fast) pk = __builtin_amdgcn_cvt_pk_u8_f32(f, i, pk);  // ReLU + RNE + sat + pack
-            else pk |= sat_u8_bits(cvt_x86_rt(relu_x86(f), a.rm0)) << (8 * i);
+            for (int i = 0; i < 4; i += 2) {
+              v2f x = {__int2float_rn(acc0[r][4 * q + i]), __int2float_rn(acc0[r][4 * q + i + 1])};
+              x = (x + v2f{bs[i], bs[i + 1]}) * v2f{sc[i], sc[i + 1]};
+              pk = __builtin_amdgcn_cvt_pk_u8_f32(x[0], i, pk);
+              pk = __builtin_amdgcn_cvt_pk_u8_f32(x[1], i + 1, pk);
+            }
+            mid[r][q] = (int)(pk ^ 0x80808080u);
           }
-          mid[r][q] = (int)(pk ^ 0x80808080u);
-        }
-
+      } else {
+#pragma unroll
+        for (int r = 0; r < OCB; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int ch = 32 * r + 8 * q + h4;
+            const v4f cp = *reinterpret_cast<const v4f *>(comp0 + ch);
+            const v4f bs = *reinterpret_cast<const v4f *>(bias0 + ch);
+            const v4f sc = *reinterpret_cast<const v4f *>(scale0 + ch);
+            unsigned pk = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float f = __fmul_rn(acc_to_f32(acc0[r][4 * q + i], cp[i], bs[i]), sc[i]);
+              pk |= sat_u8_bits(cvt_x86_rt(relu_x86(f), a.rm0)) << (8 * i);
+            }
+            mid[r][q] = (int)(pk ^ 0x80808080u);
+          }
+      }
       DFX_STAMP(c4);
       DFX_ACC(2, c4 - c3);  // requant 0
       // ---- conv1 + requant 1 + store, G column blocks at a time ----
@@ -427,14 +503,25 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
           bs[cc] = bias1[chb + cc];
           sc[cc] = scale1[chb + cc];
         }
+        // All W1 fragments of the group are fetched into DISTINCT registers before the
+        // MFMA chain starts, and the chain is fenced off from the loads: no register
+        // that an in-flight MFMA reads as A/B is the destination of a later LDS load.
+        // (With the fragments rotating through two register quads, back-to-back MFMAs
+        // followed by a reload of the second one's B operand produced rare wrong
+        // accumulators on the first launches of a process on gfx950.)
+        v4i wf[OCB][G];
 #pragma unroll
         for (int r = 0; r < OCB; ++r)
 #pragma unroll
-          for (int cc = 0; cc < G; ++cc) {
-            const v4i w = *reinterpret_cast<const v4i *>(
+          for (int cc = 0; cc < G; ++cc)
+            wf[r][cc] = *reinterpret_cast<const v4i *>(
                 w1s + ((cg * G + cc) * OCB + r) * 1024 + lane16);
-            acc1[cc] = mfma_i8(mid[r], w, acc1[cc]);
-          }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < OCB; ++r)
+#pragma unroll
+          for (int cc = 0; cc < G; ++cc) acc1[cc] = mfma_i8(mid[r], wf[r][cc], acc1[cc]);
+        __builtin_amdgcn_sched_barrier(0);
         // register e of the accumulator = pixel 8*(e>>2) + 4h + (e&3) of the tile
         const unsigned lane_off = (unsigned)h4 * row_bytes + (unsigned)chb * ESZ;
         auto emit = [&](auto fast_tag, auto check_tag) {
@@ -446,7 +533,7 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
 #pragma unroll
               for (int cc = 0; cc < G; ++cc) v[cc] = acc1[cc][e];
               store_group<DST, G, decltype(fast_tag)::value>(
-                  tile_dst + (size_t)(lane_off + (unsigned)pl * row_bytes), v, cp, bs, sc, relu1, a.rm1);
+                  (tile_dst + (size_t)((unsigned)pl * row_bytes)) + lane_off, v, cp, bs, sc, relu1, a.rm1);
             }
           }
         };
@@ -460,16 +547,23 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
       DFX_ACC(6, 1);
     }
     DFX_STAMP(c6);
-    __syncthreads();  // (B) every compute wave is done reading this unit's halo tile
-    DFX_STAMP(c7);
-    DFX_ACC(4, c7 - c6);  // wait at barrier B
-    DFX_ACC(5, c7 - c0);  // whole unit
+    // this wave is done with buffer b (its LDS reads have been consumed by the MFMAs)
+    // (one add per WAVE: lane 0 only)
+    if (lane == 0) __hip_atomic_fetch_add(done + b, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    DFX_ACC(5, c6 - c0);  // whole unit
     DFX_ACC(7, 1);
-    unit = next;
   }
 #ifdef DFX_STAMPS
-  if (lane == 0)
-    for (int k = 0; k < 8; ++k) g.prof[((size_t)blockIdx.x * 8 + wave) * 8 + k] = prof_acc[k];
+  {
+    DFX_STAMP(t_end);
+    unsigned long long rt;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
+    if (lane == 0) {
+      unsigned long long *o = g.prof + ((size_t)blockIdx.x * 16 + wave) * 16;
+      for (int k = 0; k < 8; ++k) o[k] = prof_acc[k];
+      o[8] = t_entry; o[9] = t_end; o[10] = rt;
+    }
+  }
 #endif
 }
 

@@ -212,50 +212,49 @@ static size_t round16(size_t v) { return (v + 15) & ~(size_t)15; }
 static bool pick_geometry(const dfx_conv_desc &d, MfmaGeom &g, int &lds) {
   const int ICB = d.ic / 32, OCB = d.oc / 32, NCB = d.oc1x1 / 32;
   const size_t fixed = (size_t)OCB * 9 * ICB * 1024 + (size_t)NCB * OCB * 1024 +
-                       round16((size_t)3 * (d.oc + d.oc1x1) * 4 + 16);
-  const size_t budgets[2] = {81920, 163840};  // two / one workgroup(s) per CU
-  // rows per unit wanted for parallelism: aim for >= ~1024 units
-  int th_par = (int)(((long long)d.bs * d.oh) / 1024);
+                       round16((size_t)3 * (d.oc + d.oc1x1) * 4) + MFMA_CTRL_BYTES;
+  const size_t lds_max = 163840;  // one workgroup per CU owns the whole LDS
+  if (fixed + 4 * 1024 > lds_max) return false;
+  const size_t tile_max = (lds_max - fixed) / (2 * MFMA_TEAMS);  // four tile buffers
+  // rows per unit wanted for parallelism: aim for >= ~3 units per team (512 teams)
+  int th_par = (int)(((long long)d.bs * d.oh) / 1536);
   if (th_par < 1) th_par = 1;
-  if (th_par < 2 && (long long)d.bs * d.oh / 2 >= 256) th_par = 2;
+  if (th_par < 2 && (long long)d.bs * d.oh / 2 >= 512) th_par = 2;
   if (th_par > 16) th_par = 16;
-  for (size_t budget : budgets) {
-    if (fixed >= budget) continue;
-    double best = -1.0;
-    for (int mode = 0; mode < 2; ++mode)
-      for (int tw = (mode == 0 ? d.ow : 32); tw <= (mode == 0 ? d.ow : std::min(d.ow, 256)); tw += 32) {
-        if (mode == 1 && tw >= d.ow) break;  // full width is mode 0
-        for (int th = 1; th <= std::min(d.oh, th_par); ++th) {
-          const size_t tile = (size_t)(th + 2) * (tw + 2) * d.ic + 16;  // +16: the loader's dump slot
-          if (fixed + tile > budget) break;
-          const int npx = th * tw;
-          const int ntiles = mode == 0 ? (npx + 31) / 32 : th * (tw / 32);
-          const int rounds = (ntiles + MFMA_CW - 1) / MFMA_CW;
-          const double px_eff = (double)npx / (32.0 * ntiles);
-          const double wave_eff = (double)ntiles / (MFMA_CW * rounds);
-          const double halo_eff = (double)npx / ((th + 2.0) * (tw + 2.0));
-          // edge units are partial: fraction of the covered area that is real output
-          const double cover = ((double)d.oh * d.ow) /
-                               ((double)((d.oh + th - 1) / th * th) * ((d.ow + tw - 1) / tw * tw));
-          const bool oversize = (tile - 16) / 16 > (size_t)64 * MFMA_LC;
-          const double score = px_eff * wave_eff * cover * (0.75 + 0.25 * halo_eff) * (oversize ? 0.9 : 1.0);
-          if (score > best) {
-            best = score;
-            g.th = th; g.tw = tw; g.linear = mode == 0;
-          }
+  double best = -1.0;
+  for (int mode = 0; mode < 2; ++mode)
+    for (int tw = (mode == 0 ? d.ow : 32); tw <= (mode == 0 ? d.ow : std::min(d.ow, 256)); tw += 32) {
+      if (mode == 1 && tw >= d.ow) break;  // full width is mode 0
+      for (int th = 1; th <= std::min(d.oh, th_par); ++th) {
+        const size_t tile = (size_t)(th + 2) * (tw + 2) * d.ic + 16;  // +16: the loader's dump slot
+        if (tile > tile_max) break;
+        const int npx = th * tw;
+        const int ntiles = mode == 0 ? (npx + 31) / 32 : th * (tw / 32);
+        const int rounds = (ntiles + MFMA_CW - 1) / MFMA_CW;
+        const double px_eff = (double)npx / (32.0 * ntiles);
+        const double wave_eff = (double)ntiles / (MFMA_CW * rounds);
+        const double halo_eff = (double)npx / ((th + 2.0) * (tw + 2.0));
+        // edge units are partial: fraction of the covered area that is real output
+        const double cover = ((double)d.oh * d.ow) /
+                             ((double)((d.oh + th - 1) / th * th) * ((d.ow + tw - 1) / tw * tw));
+        const bool oversize = (tile - 16) / 16 > (size_t)64 * MFMA_LC;
+        const double score = px_eff * wave_eff * cover * (0.75 + 0.25 * halo_eff) * (oversize ? 0.9 : 1.0);
+        if (score > best) {
+          best = score;
+          g.th = th; g.tw = tw; g.linear = mode == 0;
         }
       }
-    if (best < 0) continue;
-    g.uy = (d.oh + g.th - 1) / g.th;
-    g.ux = (d.ow + g.tw - 1) / g.tw;
-    g.total_units = d.bs * g.uy * g.ux;
-    g.row_chunks = (g.tw + 2) * (d.ic / 16);
-    g.tile_chunks = (g.th + 2) * g.row_chunks;
-    g.row_magic = (unsigned)(((1ull << 32) + g.row_chunks - 1) / g.row_chunks);
-    lds = (int)(fixed + (size_t)g.tile_chunks * 16 + 16);
-    return true;
-  }
-  return false;
+    }
+  if (best < 0) return false;
+  g.uy = (d.oh + g.th - 1) / g.th;
+  g.ux = (d.ow + g.tw - 1) / g.tw;
+  g.total_units = d.bs * g.uy * g.ux;
+  g.row_chunks = (g.tw + 2) * (d.ic / 16);
+  g.tile_chunks = (g.th + 2) * g.row_chunks;
+  g.row_magic = (unsigned)(((1ull << 32) + g.row_chunks - 1) / g.row_chunks);
+  g.tile_stride = g.tile_chunks * 16 + 16;
+  lds = (int)(fixed + (size_t)2 * MFMA_TEAMS * g.tile_stride);
+  return true;
 }
 
 static bool mfma_eligible(const dfx_conv_desc &d) {
@@ -314,9 +313,9 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
         delete h;
         return fail(DFX_ERR_HIP, "conv_create: cannot query the device");
       }
-      const int per_cu = h->lds <= 81920 ? 2 : 1;  // persistent workgroups resident per CU
-      h->grid = prop.multiProcessorCount * per_cu;
-      if (h->grid > h->geom.total_units) h->grid = h->geom.total_units;
+      h->grid = prop.multiProcessorCount;  // one persistent workgroup (two teams) per CU
+      const int want = (h->geom.total_units + MFMA_TEAMS - 1) / MFMA_TEAMS;
+      if (h->grid > want) h->grid = want;
     }
     h->block = MFMA_THREADS;
     if (hipMalloc((void **)&h->d_queue, 16) != hipSuccess ||
@@ -326,9 +325,13 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     }
     h->geom.queue = h->d_queue;
     h->geom.fast = 0;
+    {
+      const int teams = h->grid * MFMA_TEAMS;
+      h->geom.static_rounds = std::max(0, h->geom.total_units / teams - 1);
+    }
 #ifdef DFX_STAMPS
-    if (hipMalloc((void **)&h->d_prof, (size_t)h->grid * 64 * 8) != hipSuccess ||
-        hipMemset(h->d_prof, 0, (size_t)h->grid * 64 * 8) != hipSuccess) {
+    if (hipMalloc((void **)&h->d_prof, (size_t)h->grid * 256 * 8) != hipSuccess ||
+        hipMemset(h->d_prof, 0, (size_t)h->grid * 256 * 8) != hipSuccess) {
       delete h;
       return fail(DFX_ERR_HIP, "conv_create: cannot allocate the stamp buffer");
     }
@@ -426,13 +429,19 @@ int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei, const void *bia0, con
       for (int oc = 0; oc < OC; ++oc) s += wei1[dfx_blocked_offset(o1, oc, 0, 0, OC, 1, 1)];
       comp1[o1] = (float)(128 * s);
     }
-    // Fast requant path: both stages round to nearest-even and, from the weights
-    // themselves, no value can be NaN or reach +-2^31 before vcvtps2dq, so the x86
-    // overflow/NaN selects can never fire.  |acc| <= 255 * max(sum w+, -sum w-).
+    // Fast requant path (conv_mfma.cuh, store_group<FAST>): both stages round to
+    // nearest-even; from the weights themselves no value can be NaN or reach +-2^31
+    // before vcvtps2dq (|acc| <= 255 * max(sum w+, -sum w-)); and comp + bias folds into
+    // ONE exact f32 add: bias integer-valued, |comp + bias| < 2^24 and |acc + bias| < 2^24,
+    // so float(acc) + float(bias) of the reference == float(raw) + float(comp + bias).
     bool fast = d.conv0_round_mode == DFX_ROUND_NEAREST && d.conv1_round_mode == DFX_ROUND_NEAREST;
-    auto bounded = [](double amax, float bias, float scale) {
+    auto ok_channel = [](double amax, float comp, float bias, float scale) {
       if (!std::isfinite(bias) || !std::isfinite(scale)) return false;
-      return (amax + std::fabs((double)bias)) * std::fabs((double)scale) * 1.0001 + 2.0 < 2147480000.0;
+      const double b = bias;
+      if (b != std::floor(b)) return false;                       // integer-valued bias only
+      const double lim = 16777216.0;                              // 2^24
+      if (std::fabs((double)comp + b) >= lim || amax + std::fabs(b) >= lim) return false;
+      return (amax + std::fabs(b)) * std::fabs((double)scale) * 1.0001 + 2.0 < 2147480000.0;
     };
     for (int oc = 0; oc < OC && fast; ++oc) {
       double pos = 0, neg = 0;
@@ -441,7 +450,7 @@ int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei, const void *bia0, con
           const int w = wei[dfx_blocked_offset(oc, ic, tap / 3, tap % 3, IC, 3, 3)];
           (w > 0 ? pos : neg) += w;
         }
-      fast = bounded(255.0 * std::max(pos, -neg), b0[oc], s0[oc]);
+      fast = ok_channel(255.0 * std::max(pos, -neg), comp0[oc], b0[oc], s0[oc]);
     }
     for (int o1 = 0; o1 < OC1 && fast; ++o1) {
       double pos = 0, neg = 0;
@@ -449,7 +458,11 @@ int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei, const void *bia0, con
         const int w = wei1[dfx_blocked_offset(o1, oc, 0, 0, OC, 1, 1)];
         (w > 0 ? pos : neg) += w;
       }
-      fast = bounded(255.0 * std::max(pos, -neg), b1[o1], s1[o1]);
+      fast = ok_channel(255.0 * std::max(pos, -neg), comp1[o1], b1[o1], s1[o1]);
+    }
+    if (fast) {  // the fast path reads comp + bias from the bias slot
+      for (int oc = 0; oc < OC; ++oc) b0[oc] = comp0[oc] + b0[oc];
+      for (int o1 = 0; o1 < OC1; ++o1) b1[o1] = comp1[o1] + b1[o1];
     }
     h->geom.fast = fast ? 1 : 0;
   } else {
@@ -541,7 +554,7 @@ int dfx_conv_query(const dfx_conv_t *h, dfx_conv_info *info) {
 // diagnostic build only: copies the [grid][8 waves][8] stamp sums of the last launch
 int dfx_debug_read_stamps(dfx_conv_t *h, unsigned long long *out, int max_entries) {
   if (!h || !h->d_prof) return fail(DFX_ERR_STATE, "no stamps");
-  int n = h->grid * 64;
+  int n = h->grid * 256;
   if (n > max_entries) n = max_entries;
   HIP_TRY(hipMemcpy(out, h->d_prof, (size_t)n * 8, hipMemcpyDeviceToHost));
   return n;

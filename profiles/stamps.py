@@ -32,21 +32,25 @@ torch.cuda.synchronize()
 L = capi.lib()
 L.dfx_debug_read_stamps.restype = ctypes.c_int
 L.dfx_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
-buf = np.zeros(info.grid * 64, dtype=np.uint64)
+buf = np.zeros(info.grid * 256, dtype=np.uint64)
 # the kernel overwrites (not accumulates across launches): values are of the last launch
 n = L.dfx_debug_read_stamps(op._h, buf.ctypes.data_as(ctypes.c_void_p), buf.size)
-p = buf[:n].reshape(info.grid, 8, 8).astype(np.float64)
-comp, load = p[:, :7, :], p[:, 7, :]
+p = buf[:n].reshape(info.grid, 2, 8, 16).astype(np.float64)
+comp = p[:, :, :7, :]
 print("kernel", info.kernel_name.decode(), "grid", info.grid, "rows/unit", info.rows_per_unit)
-units = comp[:, :, 7].mean()
-print("units per workgroup (mean): %.2f, tiles per compute wave: %.2f" % (units, comp[:, :, 6].mean()))
-names = ["wait barrier A", "conv0 MFMA", "requant0", "conv1+requant1+stores", "wait barrier B", "whole unit"]
-tot = comp[:, :, 5].sum()
+units = comp[..., 7].mean()
+print("units per team (mean): %.2f (min %.0f max %.0f), tiles per compute wave: %.2f" % (
+    units, comp[..., 7].min(), comp[..., 7].max(), comp[..., 6].mean()))
+names = ["wait for tile", "conv0 MFMA", "requant0", "conv1+requant1+stores", "-", "whole unit"]
+print("start-up (entry -> unit loop): mean %.0f cycles" % comp[..., 4].mean())
+life = comp[..., 9] - comp[..., 8]
+print("wave lifetime entry->exit: mean %.0f  min %.0f  max %.0f cycles" % (life.mean(), life.min(), life.max()))
+rt = comp[..., 10]
+print("exit time spread over all compute waves (s_memrealtime @100MHz): %.2f us; per-WG entry spread n/a" % ((rt.max() - rt.min()) / 100.0))
+tot = comp[..., 5].sum()
 for k, nm in enumerate(names):
-    print("compute waves  %-24s %10.0f cycles/unit/wave  %5.1f%%" % (nm, comp[:, :, k].sum() / comp[:, :, 7].sum(),
-                                                                  100 * comp[:, :, k].sum() / tot))
-print("compute waves  per tile: conv0 %.0f  requant0 %.0f  conv1+epi %.0f" % tuple(
-    comp[:, :, k].sum() / comp[:, :, 6].sum() for k in (1, 2, 3)))
-names = ["LDS write (+load wait)", "queue atomic", "barrier A", "issue prefetch", "barrier B (= compute)"]
-for k, nm in enumerate(names):
-    print("loader wave    %-24s %10.0f cycles/unit" % (nm, load[:, k].sum() / load[:, 7].sum()))
+    if nm == "-":
+        continue
+    print("compute waves  %-24s %10.0f cycles/unit/wave  %5.1f%%" % (nm, comp[..., k].sum() / comp[..., 7].sum(),
+                                                                  100 * comp[..., k].sum() / tot))
+print("per-wave total in unit loop: mean %.0f  max %.0f cycles" % (comp[..., 5].mean(), comp[..., 5].max()))
