@@ -1,0 +1,373 @@
+// deepfusion.cc -- implementation of include/deepfusion.h on top of the C ABI
+// (include/dfx.h, libdfx_hip.so).  Host-side counterpart of the reference's
+//   src/deepfusion.cc   memory, op::submit, the dtype-switch factories (:59-185)
+//   src/op_conv.h       construction-time checks + buffer capture (:34-96)
+//   src/op_concat.h     (:28-61)
+//   util/memory.cc      aligned_malloc/free (:21-40)   -> pinned host + device buffers
+//   util/log.h          error_and_exit (:38-42)        -> same exit-on-failure behaviour
+// One op::submit() is one kernel launch on the op's HIP stream (the reference
+// runs OpenMP loops of per-row JIT calls, op_conv.cc:140-260).
+#include "deepfusion.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "dfx.h"
+
+namespace deepfusion {
+
+namespace {
+
+[[noreturn]] void error_and_exit(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  fprintf(stderr, "[deepfusion] ");
+  vfprintf(stderr, fmt, ap);
+  fprintf(stderr, "\n");
+  va_end(ap);
+  exit(EXIT_FAILURE);  // reference: util/log.h:38-42
+}
+
+void check_dfx(int rc, const char *what) {
+  if (rc != DFX_OK) error_and_exit("%s failed (%d): %s", what, rc, dfx_last_error());
+}
+
+size_t dtype_size(memory::dtype dt) {  // util/memory.cc:42-56
+  switch (dt) {
+    case memory::dtype::f32:
+    case memory::dtype::s32: return 4;
+    case memory::dtype::s8:
+    case memory::dtype::u8: return 1;
+    default: error_and_exit("Unknown data type");
+  }
+}
+
+int to_dfx_dtype(memory::dtype dt) { return static_cast<int>(dt); }  // same numbering
+
+// logical nchw -> physical dim order (reference deepfusion.cc:25-57)
+memory::dims physical_dims(const memory::nchw_dims &dm, memory::format fmt) {
+  switch (fmt) {
+    case memory::format::nhwc: return {dm[0], dm[2], dm[3], dm[1]};
+    case memory::format::nchw:
+    case memory::format::OIhw4i16o4i:
+    case memory::format::gOIhw4i16o4i: return {dm[0], dm[1], dm[2], dm[3]};
+    default: error_and_exit("bad type");
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// memory
+// ---------------------------------------------------------------------------
+
+namespace detail {
+
+struct memory_state {
+  void *host = nullptr;    // pinned
+  void *device = nullptr;  // lazily allocated
+  size_t bytes = 0;
+  unsigned long long host_version = 1;      // bumped by every data() call
+  unsigned long long uploaded_version = 0;  // host_version the device copy reflects
+};
+
+// shared plumbing of the two ops: access to the tensors' private state
+struct op_state {
+  dfx_stream_t stream = nullptr;
+
+  static memory_state *st(memory &m) { return m.st_; }
+
+  void ensure_stream() {
+    if (!stream) check_dfx(dfx_stream_create(&stream), "stream create");
+  }
+  // make the device copy of `m` current; returns the device pointer
+  void *sync_in(memory &m) {
+    memory_state *s = m.st_;
+    if (!s->device) check_dfx(dfx_mem_alloc_device(&s->device, s->bytes), "device alloc");
+    if (s->uploaded_version != s->host_version) {
+      check_dfx(dfx_memcpy_h2d(s->device, s->host, s->bytes, stream), "H2D copy");
+      s->uploaded_version = s->host_version;
+    }
+    return s->device;
+  }
+  void *device_out(memory &m) {
+    memory_state *s = m.st_;
+    if (!s->device) check_dfx(dfx_mem_alloc_device(&s->device, s->bytes), "device alloc");
+    return s->device;
+  }
+  // the op has just (re)written m on the device: the host copy is stale until downloaded
+  void fetch_out(memory &m) {
+    memory_state *s = m.st_;
+    check_dfx(dfx_memcpy_d2h(s->host, s->device, s->bytes, stream), "D2H copy");
+    s->uploaded_version = s->host_version;  // host == device after the copy
+  }
+  ~op_state() {
+    if (stream) dfx_stream_destroy(stream);
+  }
+};
+
+}  // namespace detail
+
+memory::memory(const nchw_dims &dm, const format fmt, const dtype dt, int alignment)
+    : st_(nullptr), std_dims_(dm), fmt_(fmt), dt_(dt) {
+  dims_ = physical_dims(dm, fmt);
+  allocate_buffer(alignment);
+}
+
+memory::memory(const dims &dm, const format fmt, const dtype dt, int alignment)
+    : st_(nullptr), dims_(dm), fmt_(fmt), dt_(dt) {
+  // the reference leaves std_dims_ uninitialised here although bias checks read
+  // it; give it the obvious meaning for 1-D tensors
+  std_dims_ = {dm.size() > 0 ? dm[0] : 0, dm.size() > 1 ? dm[1] : 1, dm.size() > 2 ? dm[2] : 1,
+               dm.size() > 3 ? dm[3] : 1};
+  allocate_buffer(alignment);
+}
+
+memory::~memory() {
+  if (!st_) return;
+  dfx_mem_free_host(st_->host);
+  dfx_mem_free_device(st_->device);
+  delete st_;
+}
+
+void memory::allocate_buffer(int /*alignment: pinned allocations are page aligned*/) {
+  if (buffer_size() == 0) error_and_exit("memory: empty buffer");
+  st_ = new detail::memory_state();
+  st_->bytes = buffer_size();
+  check_dfx(dfx_mem_alloc_host(&st_->host, st_->bytes), "pinned host alloc");
+}
+
+size_t memory::size() {
+  size_t n = 1;
+  for (int d : dims_) n *= static_cast<size_t>(d);
+  return n;
+}
+
+size_t memory::buffer_size() { return size() * dtype_size(dt_); }
+
+void *memory::data() {
+  ++st_->host_version;  // the caller may write through the pointer
+  return st_->host;
+}
+const void *memory::host_data() const { return st_->host; }
+unsigned long long memory::host_version() const { return st_->host_version; }
+
+void *memory::device_data() {
+  if (!st_->device) check_dfx(dfx_mem_alloc_device(&st_->device, st_->bytes), "device alloc");
+  return st_->device;
+}
+void memory::upload() {
+  check_dfx(dfx_memcpy_h2d(device_data(), st_->host, st_->bytes, nullptr), "H2D copy");
+  check_dfx(dfx_stream_sync(nullptr), "sync");
+  st_->uploaded_version = st_->host_version;
+}
+void memory::download() {
+  check_dfx(dfx_memcpy_d2h(st_->host, device_data(), st_->bytes, nullptr), "D2H copy");
+  check_dfx(dfx_stream_sync(nullptr), "sync");
+  st_->uploaded_version = st_->host_version;
+}
+
+// ---------------------------------------------------------------------------
+// op base
+// ---------------------------------------------------------------------------
+
+void op::submit() { infer(); }
+void op::submit_async() { infer(); }
+void op::wait() {}
+
+namespace {
+
+// ---- conv: replaces op_conv<T> ----
+class op_conv : public op {
+public:
+  op_conv(const std::unique_ptr<memory> &src, const std::unique_ptr<memory> &wei,
+          const std::unique_ptr<memory> &bia, std::array<int, 2> stride, std::array<int, 2> pad,
+          std::unique_ptr<memory> &dst, const std::vector<float> &scales0,
+          const std::vector<float> &scales1, const std::unique_ptr<memory> &wei1x1,
+          const std::unique_ptr<memory> &bia1x1, bool relu0, bool relu1, round_mode rm0,
+          round_mode rm1)
+      : src_(src.get()), wei_(wei.get()), bia_(bia.get()), wei1_(wei1x1.get()), bia1_(bia1x1.get()),
+        dst_(dst.get()), scales0_(scales0), scales1_(scales1), h_(nullptr), wei_seen_(0) {
+    using fmt = memory::format;
+    if (!src_ || !wei_ || !dst_) error_and_exit("Init Conv op failed! (null tensor)");
+    // dtype / format gate of jit_conv_kernel::init_conf (jit_conv_kernel.cc:531-564)
+    bool ok = src_->data_type() == memory::dtype::u8 && wei_->data_type() == memory::dtype::s8 &&
+              (!wei1_ || wei1_->data_type() == memory::dtype::s8) && src_->dim_format() == fmt::nhwc &&
+              dst_->dim_format() == fmt::nhwc &&
+              (wei_->dim_format() == fmt::OIhw4i16o4i || wei_->dim_format() == fmt::gOIhw4i16o4i) &&
+              (!wei1_ || wei1_->dim_format() == fmt::OIhw4i16o4i ||
+               wei1_->dim_format() == fmt::gOIhw4i16o4i) &&
+              (!bia_ || bia_->dim_format() == fmt::x) && (!bia1_ || bia1_->dim_format() == fmt::x);
+    if (!ok) error_and_exit("Init Conv op failed! (data type / format)");
+    auto s = src_->std_dims(), w = wei_->std_dims(), o = dst_->std_dims();
+    // shape checks of op_conv<T>::init_conf (op_conv.cc:286-346)
+    if (s[0] != o[0]) error_and_exit("Init Conv op failed! (Batch size do not equal)");
+    if (s[1] != w[1]) error_and_exit("Init Conv op failed! (Input channel do not match)");
+    dfx_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.bs = s[0]; d.ic = s[1]; d.ih = s[2]; d.iw = s[3];
+    d.oc = w[0]; d.kh = w[2]; d.kw = w[3];
+    d.oh = o[2]; d.ow = o[3];
+    d.sh = stride[0]; d.sw = stride[1]; d.pad_t = pad[0]; d.pad_l = pad[1];
+    if (wei1_) {
+      auto w1 = wei1_->std_dims();
+      if (w1[1] != w[0]) error_and_exit("Init Conv op failed! (Conv0 output channel do not match)");
+      if (o[1] != w1[0]) error_and_exit("Init Conv op failed! (Conv1x1 output channel do not match)");
+      if (w1[2] != 1 || w1[3] != 1) error_and_exit("Init Conv op failed! (Fused conv must be 1x1 kernel)");
+      if (bia1_ && (int)bia1_->size() != o[1]) error_and_exit("Init Conv op failed! (Bias channel do not match)");
+      d.oc1x1 = w1[0];
+    } else {
+      if (o[1] != w[0]) error_and_exit("Init Conv op failed! (Output channel do not match)");
+    }
+    if (bia_ && (int)bia_->size() != w[0]) error_and_exit("Init Conv op failed! (Bias channel do not match)");
+    d.dst_dt = to_dfx_dtype(dst_->data_type());
+    d.bia0_dt = bia_ ? to_dfx_dtype(bia_->data_type()) : DFX_UNDEF;
+    d.bia1_dt = bia1_ ? to_dfx_dtype(bia1_->data_type()) : DFX_UNDEF;
+    d.conv0_relu = relu0; d.conv1_relu = relu1;
+    d.conv0_round_mode = rm0 == round_mode::down ? DFX_ROUND_DOWN : DFX_ROUND_NEAREST;
+    d.conv1_round_mode = rm1 == round_mode::down ? DFX_ROUND_DOWN : DFX_ROUND_NEAREST;
+    d.conv0_nscales = (int)scales0_.size();
+    d.conv1_nscales = wei1_ ? (int)scales1_.size() : 1;
+    d.force_variant = -1;
+    if (dfx_conv_create(&d, &h_) != DFX_OK) error_and_exit("Init Conv op failed! (%s)", dfx_last_error());
+    st_.ensure_stream();
+  }
+  ~op_conv() override { dfx_conv_destroy(h_); }
+
+  void submit() override {
+    infer();
+    st_.fetch_out(*dst_);
+    check_dfx(dfx_stream_sync(st_.stream), "stream sync");
+  }
+  void submit_async() override { infer(); }
+  void wait() override { check_dfx(dfx_stream_sync(st_.stream), "stream sync"); }
+
+protected:
+  void infer() override {
+    // weights are borrowed host tensors the caller may rewrite between submits
+    // (the reference re-reads them on every call): re-pack them when any of them
+    // has been touched through data() since the last upload
+    unsigned long long v = wei_->host_version() + (bia_ ? bia_->host_version() : 0) +
+                           (wei1_ ? wei1_->host_version() : 0) + (bia1_ ? bia1_->host_version() : 0);
+    if (v != wei_seen_) {
+      check_dfx(dfx_stream_sync(st_.stream), "stream sync");  // no launch may still read the old copy
+      check_dfx(dfx_conv_set_weights(h_, (const int8_t *)wei_->host_data(),
+                                     bia_ ? bia_->host_data() : nullptr, scales0_.data(),
+                                     wei1_ ? (const int8_t *)wei1_->host_data() : nullptr,
+                                     bia1_ ? bia1_->host_data() : nullptr, scales1_.data()),
+                "conv set_weights");
+      wei_seen_ = v;
+    }
+    void *s = st_.sync_in(*src_);
+    void *o = st_.device_out(*dst_);
+    check_dfx(dfx_conv_submit(h_, s, o, st_.stream), "conv submit");
+  }
+  const char *name() override { return "conv"; }
+
+private:
+  memory *src_, *wei_, *bia_, *wei1_, *bia1_, *dst_;
+  std::vector<float> scales0_, scales1_;  // owned copies (the reference keeps a dangling pointer)
+  dfx_conv_t *h_;
+  unsigned long long wei_seen_;
+  detail::op_state st_;
+};
+
+// ---- concat: replaces op_concat<T> ----
+class op_concat : public op {
+public:
+  op_concat(const std::vector<std::unique_ptr<memory>> &srcs, std::unique_ptr<memory> &dst, bool relu)
+      : dst_(dst.get()), h_(nullptr) {
+    if (!dst_ || srcs.empty()) error_and_exit("Init Concat op failed!");
+    if (dst_->dim_format() != memory::format::nhwc) error_and_exit("Init Concat op failed! (format)");
+    auto dm = dst_->actual_dims();  // {n,h,w,c}
+    std::vector<int32_t> ch;
+    int total = 0;
+    for (auto &m : srcs) {
+      // jit_concat_kernel::init_conf (jit_concat_kernel.cc:178-191)
+      if (!m || m->dim_format() != dst_->dim_format() || m->data_type() != dst_->data_type())
+        error_and_exit("Init Concat op failed! (format / data type)");
+      auto sd = m->actual_dims();
+      if (sd[0] != dm[0] || sd[1] != dm[1] || sd[2] != dm[2]) error_and_exit("Init Concat op failed! (shape)");
+      srcs_.push_back(m.get());
+      ch.push_back(sd[3]);
+      total += sd[3];
+    }
+    if (total != dm[3]) error_and_exit("Init Concat op failed! (channels)");
+    dfx_concat_desc d;
+    d.n_inputs = (int)ch.size();
+    d.bs = dm[0]; d.h = dm[1]; d.w = dm[2];
+    d.dt = to_dfx_dtype(dst_->data_type());
+    d.post_relu = relu;
+    d.channels = ch.data();
+    if (dfx_concat_create(&d, &h_) != DFX_OK) error_and_exit("Init Concat op failed! (%s)", dfx_last_error());
+    st_.ensure_stream();
+  }
+  ~op_concat() override { dfx_concat_destroy(h_); }
+
+  void submit() override {
+    infer();
+    st_.fetch_out(*dst_);
+    check_dfx(dfx_stream_sync(st_.stream), "stream sync");
+  }
+  void submit_async() override { infer(); }
+  void wait() override { check_dfx(dfx_stream_sync(st_.stream), "stream sync"); }
+
+protected:
+  void infer() override {
+    std::vector<const void *> p;
+    for (memory *m : srcs_) p.push_back(st_.sync_in(*m));
+    check_dfx(dfx_concat_submit(h_, p.data(), st_.device_out(*dst_), st_.stream), "concat submit");
+  }
+  const char *name() override { return "concat"; }
+
+private:
+  std::vector<memory *> srcs_;
+  memory *dst_;
+  dfx_concat_t *h_;
+  detail::op_state st_;
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// factories (reference deepfusion.cc:105-185)
+// ---------------------------------------------------------------------------
+
+std::unique_ptr<op> concat(const std::vector<std::unique_ptr<memory>> &srcs,
+                           std::unique_ptr<memory> &dst, bool post_relu) {
+  return std::unique_ptr<op>(new op_concat(srcs, dst, post_relu));
+}
+
+std::unique_ptr<op> conv(const std::unique_ptr<memory> &src, const std::unique_ptr<memory> &wei,
+                         const std::unique_ptr<memory> &bia, std::array<int, 2> sz_stride,
+                         std::array<int, 2> sz_padding, const std::unique_ptr<memory> &wei1x1,
+                         const std::unique_ptr<memory> &bia1x1, std::unique_ptr<memory> &dst,
+                         bool conv0_relu, std::vector<float> conv0_scales, round_mode conv0_round_mode,
+                         bool conv1_relu, std::vector<float> conv1_scales, round_mode conv1_round_mode) {
+  return std::unique_ptr<op>(new op_conv(src, wei, bia, sz_stride, sz_padding, dst, conv0_scales,
+                                         conv1_scales, wei1x1, bia1x1, conv0_relu, conv1_relu,
+                                         conv0_round_mode, conv1_round_mode));
+}
+
+std::unique_ptr<op> conv(const std::unique_ptr<memory> &src, const std::unique_ptr<memory> &wei,
+                         const std::unique_ptr<memory> &bia, std::array<int, 2> sz_stride,
+                         std::array<int, 2> sz_padding, std::unique_ptr<memory> &dst, bool conv0_relu,
+                         std::vector<float> conv0_scales, round_mode conv0_round_mode) {
+  static const std::unique_ptr<memory> none;
+  return conv(src, wei, bia, sz_stride, sz_padding, none, none, dst, conv0_relu, conv0_scales,
+              conv0_round_mode);
+}
+
+void reorder_weights(const s8 *oihw, const std::unique_ptr<memory> &blocked) {
+  if (!oihw || !blocked || blocked->data_type() != memory::dtype::s8 ||
+      (blocked->dim_format() != memory::format::OIhw4i16o4i &&
+       blocked->dim_format() != memory::format::gOIhw4i16o4i))
+    error_and_exit("reorder_weights: destination must be an s8 OIhw4i16o4i memory");
+  auto d = blocked->std_dims();
+  check_dfx(dfx_reorder_oihw_to_blocked(oihw, static_cast<int8_t *>(blocked->data()), d[0], d[1], d[2],
+                                        d[3]),
+            "reorder");
+}
+
+}  // namespace deepfusion

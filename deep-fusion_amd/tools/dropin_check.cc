@@ -1,0 +1,110 @@
+// dropin_check -- exercises the drop-in C++ API (include/deepfusion.h) the way the
+// reference's tests do (test/test_concat.cc:89-108: build memories, fill through
+// data(), create the op, submit(), read dst->data()) and dumps inputs and results as
+// raw files; tests/test_dropin.py re-checks them against the CPU oracle.
+//   dropin_check <outdir>
+#include <cstdio>
+#include <string>
+
+#include "cli_flags.h"
+#include "deepfusion.h"
+
+using namespace deepfusion;
+
+static void dump(const std::string &path, const void *p, size_t bytes) {
+  FILE *f = fopen(path.c_str(), "wb");
+  if (!f || fwrite(p, 1, bytes, f) != bytes) { fprintf(stderr, "cannot write %s\n", path.c_str()); exit(2); }
+  fclose(f);
+}
+
+int main(int argc, char **argv) {
+  const std::string out = argc > 1 ? argv[1] : ".";
+  Lcg g(42);
+  // ---- fused conv: N=2, 13x13, 32 -> 32 -> 64, pad 1, u8 out, s32 bias, per-channel scale1 ----
+  {
+    const int bs = 2, ic = 32, ih = 13, iw = 13, oc = 32, oc1 = 64;
+    std::unique_ptr<memory> src(new memory(memory::nchw_dims{bs, ic, ih, iw}, memory::format::nhwc, memory::dtype::u8));
+    std::unique_ptr<memory> wei(new memory(memory::nchw_dims{oc, ic, 3, 3}, memory::format::OIhw4i16o4i, memory::dtype::s8));
+    std::unique_ptr<memory> wei1(new memory(memory::nchw_dims{oc1, oc, 1, 1}, memory::format::OIhw4i16o4i, memory::dtype::s8));
+    std::unique_ptr<memory> bia(new memory(memory::dims{oc}, memory::format::x, memory::dtype::s32));
+    std::unique_ptr<memory> bia1(new memory(memory::dims{oc1}, memory::format::x, memory::dtype::s32));
+    std::unique_ptr<memory> dst(new memory(memory::nchw_dims{bs, oc1, ih, iw}, memory::format::nhwc, memory::dtype::u8));
+    uint8_t *s = (uint8_t *)src->data();
+    for (size_t i = 0; i < src->size(); ++i) s[i] = (uint8_t)(g.next() % 17);
+    std::vector<s8> w0(wei->size()), w1(wei1->size());
+    for (auto &v : w0) v = (s8)((int)(g.next() % 21) - 10);
+    for (auto &v : w1) v = (s8)((int)(g.next() % 21) - 10);
+    reorder_weights(w0.data(), wei);
+    reorder_weights(w1.data(), wei1);
+    int32_t *b0 = (int32_t *)bia->data(), *b1 = (int32_t *)bia1->data();
+    for (int i = 0; i < oc; ++i) b0[i] = (int)(g.next() % 21) - 10;
+    for (int i = 0; i < oc1; ++i) b1[i] = (int)(g.next() % 21) - 10;
+    std::vector<float> sc1(oc1);
+    for (int i = 0; i < oc1; ++i) sc1[i] = 0.02f * (0.5f + (float)i / oc1);
+    auto c = conv(src, wei, bia, {1, 1}, {1, 1}, wei1, bia1, dst, true, {1.f / 64}, round_mode::nearest, true, sc1,
+                  round_mode::nearest);
+    c->submit();
+    dump(out + "/fused_src.bin", src->host_data(), src->buffer_size());
+    dump(out + "/fused_w0_oihw.bin", w0.data(), w0.size());
+    dump(out + "/fused_w1_oihw.bin", w1.data(), w1.size());
+    dump(out + "/fused_b0.bin", bia->host_data(), bia->buffer_size());
+    dump(out + "/fused_b1.bin", bia1->host_data(), bia1->buffer_size());
+    dump(out + "/fused_sc1.bin", sc1.data(), sc1.size() * 4);
+    dump(out + "/fused_dst.bin", dst->data(), dst->buffer_size());
+    // the caller rewrites the input through data(): the next submit must see it
+    for (size_t i = 0; i < src->size(); ++i) ((uint8_t *)src->data())[i] = (uint8_t)(16 - s[i]);
+    c->submit();
+    dump(out + "/fused_dst2.bin", dst->data(), dst->buffer_size());
+  }
+  // ---- unfused conv: N=1, 9x7, 32 -> 48, stride 2, pad 1, s8 out, no relu, round down ----
+  {
+    const int bs = 1, ic = 32, ih = 9, iw = 7, oc = 48, oh = 5, ow = 4;
+    std::unique_ptr<memory> src(new memory(memory::nchw_dims{bs, ic, ih, iw}, memory::format::nhwc, memory::dtype::u8));
+    std::unique_ptr<memory> wei(new memory(memory::nchw_dims{oc, ic, 3, 3}, memory::format::OIhw4i16o4i, memory::dtype::s8));
+    std::unique_ptr<memory> bia(new memory(memory::dims{oc}, memory::format::x, memory::dtype::s8));
+    std::unique_ptr<memory> dst(new memory(memory::nchw_dims{bs, oc, oh, ow}, memory::format::nhwc, memory::dtype::s8));
+    uint8_t *s = (uint8_t *)src->data();
+    for (size_t i = 0; i < src->size(); ++i) s[i] = (uint8_t)(g.next() % 256);
+    std::vector<s8> w0(wei->size());
+    for (auto &v : w0) v = (s8)((int)(g.next() % 255) - 127);
+    reorder_weights(w0.data(), wei);
+    s8 *b0 = (s8 *)bia->data();
+    for (int i = 0; i < oc; ++i) b0[i] = (s8)((int)(g.next() % 21) - 10);
+    auto c = conv(src, wei, bia, {2, 2}, {1, 1}, dst, false, {1.f / 4096}, round_mode::down);
+    c->submit();
+    dump(out + "/unfused_src.bin", src->host_data(), src->buffer_size());
+    dump(out + "/unfused_w0_oihw.bin", w0.data(), w0.size());
+    dump(out + "/unfused_b0.bin", bia->host_data(), bia->buffer_size());
+    dump(out + "/unfused_dst.bin", dst->data(), dst->buffer_size());
+  }
+  // ---- concat + relu: BASELINE.json configs[0] shape (4 x {1,16,8,8} f32) and an s8 case ----
+  {
+    std::vector<std::unique_ptr<memory>> srcs;
+    for (int k = 0; k < 4; ++k) {
+      srcs.emplace_back(new memory(memory::nchw_dims{1, 16, 8, 8}, memory::format::nhwc, memory::dtype::f32));
+      float *p = (float *)srcs.back()->data();
+      for (size_t i = 0; i < srcs.back()->size(); ++i) p[i] = ((int)(g.next() % 2001) - 1000) * 0.01f;
+      dump(out + "/concat_f32_src" + std::to_string(k) + ".bin", p, srcs.back()->buffer_size());
+    }
+    std::unique_ptr<memory> dst(new memory(memory::nchw_dims{1, 64, 8, 8}, memory::format::nhwc, memory::dtype::f32));
+    auto c = concat(srcs, dst, true);
+    c->submit();
+    dump(out + "/concat_f32_dst.bin", dst->data(), dst->buffer_size());
+  }
+  {
+    std::vector<std::unique_ptr<memory>> srcs;
+    const int chs[3] = {16, 32, 64};
+    for (int k = 0; k < 3; ++k) {
+      srcs.emplace_back(new memory(memory::nchw_dims{2, chs[k], 3, 3}, memory::format::nhwc, memory::dtype::s8));
+      s8 *p = (s8 *)srcs.back()->data();
+      for (size_t i = 0; i < srcs.back()->size(); ++i) p[i] = (s8)((int)(g.next() % 256) - 128);
+      dump(out + "/concat_s8_src" + std::to_string(k) + ".bin", p, srcs.back()->buffer_size());
+    }
+    std::unique_ptr<memory> dst(new memory(memory::nchw_dims{2, 112, 3, 3}, memory::format::nhwc, memory::dtype::s8));
+    auto c = concat(srcs, dst, true);
+    c->submit();
+    dump(out + "/concat_s8_dst.bin", dst->data(), dst->buffer_size());
+  }
+  printf("dropin_check wrote results to %s\n", out.c_str());
+  return 0;
+}

@@ -1,0 +1,76 @@
+"""GPU: the drop-in C++ API (include/deepfusion.h, libdeepfusion.so) used the way the
+reference's tests use it (memories filled through data(), op created, submit(), dst
+read through data()), checked bit-for-bit against the CPU oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import cases as C
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOLS = os.path.join(ROOT, "deep-fusion_amd", "tools")
+
+
+def _load(d, name, dtype, shape=None):
+    a = np.fromfile(os.path.join(d, name), dtype=dtype)
+    return a.reshape(shape) if shape else a
+
+
+def test_dropin_cpp_api(oracle, tmp_path):
+    exe = os.path.join(TOOLS, "dropin_check")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    subprocess.check_call([exe, str(tmp_path)])
+    d = str(tmp_path)
+    # fused conv
+    src = _load(d, "fused_src.bin", np.uint8, (2, 13, 13, 32))
+    w0 = _load(d, "fused_w0_oihw.bin", np.int8, (32, 32, 3, 3))
+    w1 = _load(d, "fused_w1_oihw.bin", np.int8, (64, 32, 1, 1))
+    b0 = _load(d, "fused_b0.bin", np.int32)
+    b1 = _load(d, "fused_b1.bin", np.int32)
+    sc1 = _load(d, "fused_sc1.bin", np.float32)
+    sc0 = np.array([1.0 / 64], dtype=np.float32)
+
+    def ref_fused(s):
+        return oracle.conv(s, oracle.reorder_oihw_to_blocked(w0), w0.shape, (1, 1), (1, 1), C.U8, sc0,
+                           bia0=b0, wei1_blk=oracle.reorder_oihw_to_blocked(w1), oc1x1=64, scales1=sc1,
+                           bia1=b1, relu0=True, relu1=True)
+    got = _load(d, "fused_dst.bin", np.uint8, (2, 13, 13, 64))
+    assert np.array_equal(got, ref_fused(src))
+    got2 = _load(d, "fused_dst2.bin", np.uint8, (2, 13, 13, 64))       # input rewritten via data()
+    assert np.array_equal(got2, ref_fused((16 - src.astype(np.int32)).astype(np.uint8)))
+    assert not np.array_equal(got, got2)
+    # unfused conv, stride 2, s8 out, round down
+    src = _load(d, "unfused_src.bin", np.uint8, (1, 9, 7, 32))
+    w0 = _load(d, "unfused_w0_oihw.bin", np.int8, (48, 32, 3, 3))
+    b0 = _load(d, "unfused_b0.bin", np.int8)
+    ref = oracle.conv(src, oracle.reorder_oihw_to_blocked(w0), w0.shape, (2, 2), (1, 1), C.S8,
+                      np.array([1.0 / 4096], dtype=np.float32), bia0=b0, relu0=False, rm0=1)
+    assert np.array_equal(_load(d, "unfused_dst.bin", np.int8, ref.shape), ref)
+    # concat + relu
+    srcs = [_load(d, "concat_f32_src%d.bin" % k, np.float32, (1, 8, 8, 16)) for k in range(4)]
+    ref = oracle.concat(srcs, True)
+    assert np.array_equal(_load(d, "concat_f32_dst.bin", np.float32, ref.shape).view(np.uint32), ref.view(np.uint32))
+    srcs = [_load(d, "concat_s8_src%d.bin" % k, np.int8, (2, 3, 3, c)) for k, c in enumerate((16, 32, 64))]
+    ref = oracle.concat(srcs, True)
+    assert np.array_equal(_load(d, "concat_s8_dst.bin", np.int8, ref.shape), ref)
+
+
+def test_bench_tools_run():
+    """the reference's bench flag names are accepted (bench_concat.cc:22-29, bench_conv.cc:22-37)."""
+    out = subprocess.check_output([os.path.join(TOOLS, "bench_concat"), "-n", "1", "-c", "16,16,16,16", "-h", "8",
+                                   "-w", "8", "-dtype", "f32", "-post_relu", "-burning_iter", "2", "-iter", "3"])
+    assert b"DeepFusion Concat avg time" in out
+    out = subprocess.check_output([os.path.join(TOOLS, "bench_conv"), "-bs", "2", "-ih", "28", "-iw", "28", "-kh", "3",
+                                   "-kw", "3", "-sh", "1", "-sw", "1", "-ph", "1", "-pw", "1", "-ic", "32", "-oc", "32",
+                                   "-oc1x1", "64", "-dtype", "u8", "-burning_iter", "2", "-iter", "3"])
+    assert b"DeepFusion Conv avg time" in out
+
+
+def test_init_failure_exits_like_reference(tmp_path):
+    """construction failure -> message + exit(EXIT_FAILURE) (reference op_conv.h:66-68, log.h:38-42)."""
+    r = subprocess.run([os.path.join(TOOLS, "bench_conv"), "-bs", "1", "-ih", "8", "-iw", "8", "-ic", "24", "-oc", "32",
+                        "-oc1x1", "32", "-burning_iter", "0", "-iter", "1"], capture_output=True)
+    assert r.returncode == 1 and b"[deepfusion]" in r.stderr and b"failed" in r.stderr
