@@ -55,11 +55,12 @@ def workloads():
     }
 
 
-def cpu_baseline(case, data, budget_s=12.0):
+def cpu_baseline(case, data, threads, budget_s=12.0):
     """Oracle port timed on the host cores on a bounded sample of the workload."""
     from dataclasses import replace
     from oracle import oracle as orc
     import hipref
+    orc.set_num_threads(threads)
     impl = "avx512" if orc.have_avx512_vnni() else "scalar_mt"
     n = min(case.bs, 32 if impl == "avx512" else 4)
     sub = dict(data, src=data["src"][:n])
@@ -100,6 +101,8 @@ def main():
     ap.add_argument("--dst", default=None, help="override dst dtype: u8|s8|s32|f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=-1, help="-1 auto, 0 generic, 1 mfma")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="OpenMP threads of the CPU baseline (default: min(host cpus, 16) = one GPU's CPU share)")
     args = ap.parse_args()
 
     import torch
@@ -114,8 +117,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("DFX_BENCH_BACKEND", "nccl")   # "gloo": single-GPU rehearsal of the N>1 path
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     assert world == args.gpus or world == 1 and args.gpus == 1, \
@@ -157,7 +165,8 @@ def main():
     elapsed = t1 - t0
     kern_ms = e0.elapsed_time(e1) / args.steps        # mean launch duration, HIP events
     if world > 1:
-        tt = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed, kern_ms], dtype=torch.float64,
+                          device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, kern_ms = float(tt[0]), float(tt[1])
 
@@ -170,7 +179,7 @@ def main():
         hipref.assert_bit_equal(dsts[0][:1].cpu().numpy(), ref, "bench output vs oracle")
 
     # configs[3]: op_concat + RCCL all-gather, measured outside the timed region
-    if world > 1:
+    if world > 1 and dist.get_backend() == "nccl":
         try:
             extra["concat_allgather"] = bench_concat_allgather(dfa, torch, dist, dsts[0], world, rank)
         except Exception as ex:  # never lose the main line
@@ -208,7 +217,7 @@ def main():
         }
         out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(case, data)
+            out["cpu_baseline"] = cpu_baseline(case, data, args.cpu_threads or min(os.cpu_count() or 1, 16))
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -22,29 +22,30 @@ def shard_range(n_total, rank, world):
 
 
 def gathered_offsets(bs, h, w, channels, itemsize):
-    """Byte offset of each rank's shard inside the rank-major all-gather buffer
-    (variable channel counts allowed) and the total size."""
+    """Byte offset of each rank's shard inside the rank-major all-gather buffer and the
+    buffer size.  Shards are padded to the largest one (16-byte rounded) so that ONE
+    all_gather_into_tensor moves everything; dfx_concat_submit_gathered takes arbitrary
+    16-byte-aligned offsets, so the padding is never copied out."""
     sizes = [bs * h * w * c * itemsize for c in channels]
-    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64)
-    return [int(o) for o in offs], int(sum(sizes))
+    slot = (max(sizes) + 15) // 16 * 16
+    return [r * slot for r in range(len(channels))], slot * len(channels)
 
 
 def allgather_shards(local, channels, group=None):
-    """All-gather per-rank NHWC tensors {bs,h,w,channels[rank]} into one flat
-    rank-major byte tensor on every rank.  Equal channel counts use a single
-    all_gather_into_tensor (one large collective: xGMI links are point-to-point,
-    so fewer, larger messages win); ragged counts fall back to all_gather."""
+    """All-gather per-rank NHWC tensors {bs,h,w,channels[rank]} into one flat rank-major
+    byte tensor on every rank with a single collective (xGMI links are point-to-point:
+    fewer, larger messages win).  Layout: gathered_offsets()."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    flat = local.contiguous().view(torch.uint8).reshape(-1)
-    if len(set(channels)) == 1:
-        out = torch.empty(flat.numel() * world, dtype=torch.uint8, device=flat.device)
-        dist.all_gather_into_tensor(out, flat, group=group)
-        return out
     bs, h, w, _ = local.shape
-    per_px = local.element_size()
-    parts = [torch.empty(bs * h * w * c * per_px, dtype=torch.uint8, device=flat.device)
-             for c in channels]
-    dist.all_gather(parts, flat, group=group)
-    return torch.cat(parts)
+    offs, total = gathered_offsets(bs, h, w, channels, local.element_size())
+    slot = total // world
+    flat = local.contiguous().view(torch.uint8).reshape(-1)
+    if flat.numel() != slot:
+        padded = torch.zeros(slot, dtype=torch.uint8, device=flat.device)
+        padded[:flat.numel()] = flat
+        flat = padded
+    out = torch.empty(total, dtype=torch.uint8, device=flat.device)
+    dist.all_gather_into_tensor(out, flat, group=group)
+    return out

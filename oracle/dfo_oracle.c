@@ -206,6 +206,14 @@ int dfo_conv_scalar_mt(const dfo_conv_desc *d, const uint8_t *src,
   return 0;
 }
 
+void dfo_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int dfo_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -87,6 +87,7 @@ int dfo_conv_avx512(const dfo_conv_desc *d, const uint8_t *src,
                     void *dst);
 int dfo_have_avx512_vnni(void);
 int dfo_num_threads(void);
+void dfo_set_num_threads(int n); /* OpenMP threads used by the *_mt / avx512 entry points */
 
 /* scalar reference with the (n, oh) loop under OpenMP */
 int dfo_conv_scalar_mt(const dfo_conv_desc *d, const uint8_t *src,

@@ -58,6 +58,8 @@ def lib():
         L.dfo_reorder_oihw_to_blocked.argtypes = [vp, vp] + [ctypes.c_int] * 4
         L.dfo_have_avx512_vnni.restype = ctypes.c_int
         L.dfo_num_threads.restype = ctypes.c_int
+        L.dfo_set_num_threads.restype = None
+        L.dfo_set_num_threads.argtypes = [ctypes.c_int]
         L.dfo_conv_out_size.restype = ctypes.c_int
         L.dfo_conv_out_size.argtypes = [ctypes.c_int] * 4
         _lib = L
@@ -146,3 +148,7 @@ def have_avx512_vnni():
 
 def num_threads():
     return int(lib().dfo_num_threads())
+
+
+def set_num_threads(n):
+    lib().dfo_set_num_threads(int(n))
