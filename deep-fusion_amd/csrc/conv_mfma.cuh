@@ -124,6 +124,15 @@ __device__ __forceinline__ float acc_to_f32(int raw, float comp, float bias) {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// The output is written once and never re-read by this kernel: non-temporal stores
+// keep it from displacing the input rows / weights in L2 and leave fewer dirty lines
+// to write back at the end of the kernel.
+#ifndef DFX_TEMPORAL_STORES
+#define DFX_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define DFX_STORE(ptr, val) (*(ptr) = (val))
+#endif
+
 // ---- one pixel's G consecutive channels -> one store.
 // FAST (host-proven preconditions, dfx_api.hip): both stages round to nearest-even;
 // every value is finite and |f| < 2^31, so the x86 overflow/NaN selects are dead;
@@ -156,7 +165,7 @@ __device__ __forceinline__ void store_group(unsigned char *p, const int (&acc)[G
   if (DST == DFX_F32) {
 #pragma unroll
     for (int c = 0; c < G; ++c) f[c] = relu ? relu_x86(f[c]) : f[c];
-    if (G == 4) *reinterpret_cast<v4f *>(p) = v4f{f[0], f[1], f[2], f[3]};
+    if (G == 4) DFX_STORE(reinterpret_cast<v4f *>(p), (v4f{f[0], f[1], f[2], f[3]}));
     else if (G == 2) *reinterpret_cast<float2 *>(p) = float2{f[0], f[1]};
     else *reinterpret_cast<float *>(p) = f[0];
   } else if (DST == DFX_S32) {
@@ -166,7 +175,7 @@ __device__ __forceinline__ void store_group(unsigned char *p, const int (&acc)[G
       if (FAST) v[c] = (int)__builtin_rintf(relu ? __builtin_fmaxf(f[c], 0.0f) : f[c]);
       else v[c] = cvt_x86_rt(relu ? relu_x86(f[c]) : f[c], rm);
     }
-    if (G == 4) *reinterpret_cast<v4i *>(p) = v4i{v[0], v[1], v[2], v[3]};
+    if (G == 4) DFX_STORE(reinterpret_cast<v4i *>(p), (v4i{v[0], v[1], v[2], v[3]}));
     else if (G == 2) *reinterpret_cast<int2 *>(p) = int2{v[0], v[1]};
     else *reinterpret_cast<int *>(p) = v[0];
   } else {
@@ -182,7 +191,7 @@ __device__ __forceinline__ void store_group(unsigned char *p, const int (&acc)[G
         pk |= b << (8 * c);
       }
     }
-    if (G == 4) *reinterpret_cast<unsigned *>(p) = pk;
+    if (G == 4) DFX_STORE(reinterpret_cast<unsigned *>(p), pk);
     else if (G == 2) *reinterpret_cast<unsigned short *>(p) = (unsigned short)pk;
     else *p = (uint8_t)pk;
   }
@@ -195,6 +204,10 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   DFX_STAMP(t_entry);
+#ifdef DFX_STAMPS
+  unsigned long long rt_entry;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_entry)::"memory");
+#endif
   const int OC1 = a.oc1, NCB = OC1 >> 5, NCG = NCB / G;
   unsigned char *w0s = smem;                                   // [OCB][9][ICB][64 lanes][16 B]
   unsigned char *w1s = w0s + OCB * 9 * ICB * 1024;             // [NCB][OCB][64 lanes][16 B]
@@ -224,24 +237,16 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
     const v4i *s = reinterpret_cast<const v4i *>(a.wei);
     v4i *d = reinterpret_cast<v4i *>(smem);
     const int total = OCB * 9 * ICB * 64 + NCB * OCB * 64 + (3 * (OC + OC1) * 4 + 15) / 16;
-    for (int base = 0; base < total; base += 8 * NT) {
+    for (int base = 0; base < total; base += 4 * NT) {
       const int q0 = base + ctid, last = total - 1;
       const v4i t0 = s[min(q0 + 0 * NT, last)];
       const v4i t1 = s[min(q0 + 1 * NT, last)];
       const v4i t2 = s[min(q0 + 2 * NT, last)];
       const v4i t3 = s[min(q0 + 3 * NT, last)];
-      const v4i t4 = s[min(q0 + 4 * NT, last)];
-      const v4i t5 = s[min(q0 + 5 * NT, last)];
-      const v4i t6 = s[min(q0 + 6 * NT, last)];
-      const v4i t7 = s[min(q0 + 7 * NT, last)];
       d[min(q0 + 0 * NT, last)] = t0;
       d[min(q0 + 1 * NT, last)] = t1;
       d[min(q0 + 2 * NT, last)] = t2;
       d[min(q0 + 3 * NT, last)] = t3;
-      d[min(q0 + 4 * NT, last)] = t4;
-      d[min(q0 + 5 * NT, last)] = t5;
-      d[min(q0 + 6 * NT, last)] = t6;
-      d[min(q0 + 7 * NT, last)] = t7;
     }
     if (ctid < MFMA_CTRL_BYTES / 4) ctrl[ctid] = 0;
   };
@@ -561,7 +566,7 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
     if (lane == 0) {
       unsigned long long *o = g.prof + ((size_t)blockIdx.x * 16 + wave) * 16;
       for (int k = 0; k < 8; ++k) o[k] = prof_acc[k];
-      o[8] = t_entry; o[9] = t_end; o[10] = rt;
+      o[8] = t_entry; o[9] = t_end; o[10] = rt; o[11] = rt_entry;
     }
   }
 #endif

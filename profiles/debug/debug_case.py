@@ -1,7 +1,7 @@
 """debug helper: run one named test case repeatedly and report mismatches."""
 import sys, os
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import cases as C, hipref
 from oracle import oracle as orc

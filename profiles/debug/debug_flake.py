@@ -1,7 +1,7 @@
 """debug helper: many launches of one case; which elements ever differ from the oracle."""
 import sys, os
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import torch
 import cases as C, hipref, refmath

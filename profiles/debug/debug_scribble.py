@@ -1,7 +1,7 @@
 """debug helper: scribble over every CU's LDS before each conv launch; count mismatches."""
 import sys, os, ctypes
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import torch
 import cases as C, hipref

@@ -2,7 +2,7 @@
 mismatch report GPU vs oracle vs the independent formulation and a second GPU run."""
 import sys, os
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import cases as C, hipref, refmath
 from oracle import oracle as orc

@@ -46,6 +46,9 @@ print("start-up (entry -> unit loop): mean %.0f cycles" % comp[..., 4].mean())
 life = comp[..., 9] - comp[..., 8]
 print("wave lifetime entry->exit: mean %.0f  min %.0f  max %.0f cycles" % (life.mean(), life.min(), life.max()))
 rt = comp[..., 10]
+rte = comp[..., 11]
+print("s_memtime ticks per s_memrealtime tick (10 ns): %.2f  => s_memtime runs at %.0f MHz" % ((life / (rt - rte)).mean(), (life / (rt - rte)).mean() * 100))
+print("entry time spread over all compute waves: %.2f us; kernel span first entry -> last exit: %.2f us" % ((rte.max() - rte.min()) / 100.0, (rt.max() - rte.min()) / 100.0))
 print("exit time spread over all compute waves (s_memrealtime @100MHz): %.2f us; per-WG entry spread n/a" % ((rt.max() - rt.min()) / 100.0))
 tot = comp[..., 5].sum()
 for k, nm in enumerate(names):
