@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -328,6 +329,7 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     {
       const int teams = h->grid * MFMA_TEAMS;
       h->geom.static_rounds = std::max(0, h->geom.total_units / teams - 1);
+      if (const char *e = getenv("DFX_STATIC_ROUNDS")) h->geom.static_rounds = std::min(h->geom.static_rounds, atoi(e));  // tuning aid
     }
 #ifdef DFX_STAMPS
     if (hipMalloc((void **)&h->d_prof, (size_t)h->grid * 256 * 8) != hipSuccess ||

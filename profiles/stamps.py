@@ -57,3 +57,8 @@ for k, nm in enumerate(names):
     print("compute waves  %-24s %10.0f cycles/unit/wave  %5.1f%%" % (nm, comp[..., k].sum() / comp[..., 7].sum(),
                                                                   100 * comp[..., k].sum() / tot))
 print("per-wave total in unit loop: mean %.0f  max %.0f cycles" % (comp[..., 5].mean(), comp[..., 5].max()))
+wg_life = life.reshape(info.grid, -1).max(axis=1)
+print("per-XCD (blockIdx % 8) mean WG lifetime:", [int(wg_life[x::8].mean()) for x in range(8)])
+print("per-XCD min/max:", [(int(wg_life[x::8].min()), int(wg_life[x::8].max())) for x in range(8)])
+q = np.percentile(wg_life, [0, 10, 50, 90, 100])
+print("WG lifetime percentiles 0/10/50/90/100:", [int(v) for v in q])
