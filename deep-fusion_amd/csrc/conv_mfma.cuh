@@ -197,7 +197,11 @@ __device__ __forceinline__ void store_group(unsigned char *p, const int (&acc)[G
   }
 }
 
-template <int ICB, int OCB, int G, int DST>
+// FUSED = false is the unfused conv() overload (reference deepfusion.h:121-129): the same
+// loader / tile machinery and 3x3 MFMA ring, but the contraction is oriented
+// D0[px][oc] (A = input pixels, B = weights packed with the channel permutation, G ==
+// OCB) so that lane = output channel and the typed store is coalesced like the 1x1 stage.
+template <int ICB, int OCB, int G, int DST, bool FUSED = true>
 __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvArgs a, MfmaGeom g) {
   constexpr int IC = 32 * ICB, OC = 32 * OCB, CP = IC / 16;
   constexpr int ESZ = (DST == DFX_F32 || DST == DFX_S32) ? 4 : 1;
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
   unsigned long long rt_entry;
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_entry)::"memory");
 #endif
-  const int OC1 = a.oc1, NCB = OC1 >> 5, NCG = NCB / G;
+  const int OC1 = FUSED ? a.oc1 : 0, NCB = OC1 >> 5, NCG = FUSED ? NCB / G : 1;
   unsigned char *w0s = smem;                                   // [OCB][9][ICB][64 lanes][16 B]
   unsigned char *w1s = w0s + OCB * 9 * ICB * 1024;             // [NCB][OCB][64 lanes][16 B]
   float *cst = reinterpret_cast<float *>(w1s + NCB * OCB * 1024);
@@ -366,10 +370,10 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
   const int l31 = lane & 31, h = lane >> 5;
   const float *comp0 = cst, *bias0 = cst + OC, *scale0 = cst + 2 * OC;
   const float *comp1 = cst + 3 * OC, *bias1 = cst + 3 * OC + OC1, *scale1 = cst + 3 * OC + 2 * OC1;
-  const bool relu1 = a.relu1 || DST == DFX_U8;
+  const bool relu1 = (FUSED ? a.relu1 : a.relu0) || DST == DFX_U8;  // ReLU of the stage that stores
   const bool fast = g.fast != 0;
   const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const unsigned row_bytes = (unsigned)OC1 * ESZ;  // dst bytes per pixel
+  const unsigned row_bytes = (unsigned)(FUSED ? OC1 : OC) * ESZ;  // dst bytes per pixel
 
 #ifdef DFX_STAMPS
   unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -447,12 +451,44 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
         for (int st = 0; st < NS; ++st) {
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int r = 0; r < OCB; ++r) acc0[r] = mfma_i8(fw[st & 3][r], fb[st & 3], acc0[r]);
+          for (int r = 0; r < OCB; ++r)
+            acc0[r] = FUSED ? mfma_i8(fw[st & 3][r], fb[st & 3], acc0[r])   // D0[oc][px]
+                            : mfma_i8(fb[st & 3], fw[st & 3][r], acc0[r]);  // D0[px][oc]
           __builtin_amdgcn_sched_barrier(0);
           if (st + 3 < NS) fetch(st + 3, (st + 3) & 3);
         }
       }
 
+      unsigned char *tile_dst = reinterpret_cast<unsigned char *>(a.dst) + obase * row_bytes;
+      using T = std::true_type;
+      using F = std::false_type;
+      if constexpr (!FUSED) {
+        // ---- unfused: requant 0 + typed store straight from the 3x3 accumulators ----
+        const int chb = lch;  // G == OCB: this lane owns channels G*l31 .. G*l31 + G-1
+        float cp[G], bs[G], sc[G];
+#pragma unroll
+        for (int cc = 0; cc < G; ++cc) {
+          cp[cc] = comp0[chb + cc];
+          bs[cc] = bias0[chb + cc];
+          sc[cc] = scale0[chb + cc];
+        }
+        const unsigned lane_off = (unsigned)h4 * row_bytes + (unsigned)chb * ESZ;
+        auto emit0 = [&](auto fast_tag, auto check_tag) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int pl = 8 * (e >> 2) + (e & 3);  // + 4h, folded into lane_off
+            if (!decltype(check_tag)::value || pl + 4 * h < nvalid) {
+              int v[G];
+#pragma unroll
+              for (int cc = 0; cc < G; ++cc) v[cc] = acc0[cc][e];
+              store_group<DST, G, decltype(fast_tag)::value>(
+                  (tile_dst + (size_t)((unsigned)pl * row_bytes)) + lane_off, v, cp, bs, sc, relu1, a.rm0);
+            }
+          }
+        };
+        if (fast) { if (nvalid == 32) emit0(T{}, F{}); else emit0(T{}, T{}); }
+        else      { if (nvalid == 32) emit0(F{}, F{}); else emit0(F{}, T{}); }
+      } else {
       DFX_STAMP(c3);
       DFX_ACC(1, c3 - c2);  // conv0 MFMA issue
       // ---- requant 0 in registers -> A fragments of the 1x1 ----
@@ -496,7 +532,6 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
       DFX_STAMP(c4);
       DFX_ACC(2, c4 - c3);  // requant 0
       // ---- conv1 + requant 1 + store, G column blocks at a time ----
-      unsigned char *tile_dst = reinterpret_cast<unsigned char *>(a.dst) + obase * row_bytes;
       for (int cg = 0; cg < NCG; ++cg) {
         const int chb = 32 * G * cg + lch;  // this lane's first channel in the group
         v16i acc1[G];
@@ -542,11 +577,10 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
             }
           }
         };
-        using T = std::true_type;
-        using F = std::false_type;
         if (fast) { if (nvalid == 32) emit(T{}, F{}); else emit(T{}, T{}); }
         else      { if (nvalid == 32) emit(F{}, F{}); else emit(F{}, T{}); }
       }
+      }  // FUSED
       DFX_STAMP(c5);
       DFX_ACC(3, c5 - c4);  // conv1 + requant 1 + stores
       DFX_ACC(6, 1);

@@ -32,6 +32,13 @@ DFX_DECL(s32);
 DFX_DECL(s8);
 DFX_DECL(u8);
 #undef DFX_DECL
+#define DFX_DECL(n) \
+  int launch_conv_mfma_##n##_unfused(const ConvArgs &, const MfmaGeom &, int, int, int, int, hipStream_t, int)
+DFX_DECL(f32);
+DFX_DECL(s32);
+DFX_DECL(s8);
+DFX_DECL(u8);
+#undef DFX_DECL
 
 int launch_concat(const ConcatArgs &a, hipStream_t s);
 }  // namespace dfx
@@ -258,13 +265,21 @@ static bool pick_geometry(const dfx_conv_desc &d, MfmaGeom &g, int &lds) {
   return true;
 }
 
-static bool mfma_eligible(const dfx_conv_desc &d) {
-  return d.oc1x1 > 0 && d.kh == 3 && d.kw == 3 && d.sh == 1 && d.sw == 1 && d.pad_t <= 1 &&
-         d.pad_l <= 1 && (d.ic == 32 || d.ic == 64) && (d.oc == 32 || d.oc == 64) &&
-         d.oc1x1 % 32 == 0;
+static bool mfma_eligible(const dfx_conv_desc &d) {  // fused or unfused (oc1x1 == 0)
+  return d.kh == 3 && d.kw == 3 && d.sh == 1 && d.sw == 1 && d.pad_t <= 1 && d.pad_l <= 1 &&
+         (d.ic == 32 || d.ic == 64) && (d.oc == 32 || d.oc == 64) && d.oc1x1 % 32 == 0;
 }
 
 static int mfma_dispatch(dfx_conv *h, hipStream_t s, int mode) {
+  if (h->variant == DFX_VARIANT_MFMA_CONV) {
+    switch (h->d.dst_dt) {
+      case DFX_F32: return launch_conv_mfma_f32_unfused(h->args, h->geom, h->icb, h->ocb, h->grid, h->lds, s, mode);
+      case DFX_S32: return launch_conv_mfma_s32_unfused(h->args, h->geom, h->icb, h->ocb, h->grid, h->lds, s, mode);
+      case DFX_S8: return launch_conv_mfma_s8_unfused(h->args, h->geom, h->icb, h->ocb, h->grid, h->lds, s, mode);
+      case DFX_U8: return launch_conv_mfma_u8_unfused(h->args, h->geom, h->icb, h->ocb, h->grid, h->lds, s, mode);
+    }
+    return -1;
+  }
   switch (h->d.dst_dt) {
     case DFX_F32: return launch_conv_mfma_f32(h->args, h->geom, h->icb, h->ocb, h->G, h->grid, h->lds, s, mode);
     case DFX_S32: return launch_conv_mfma_s32(h->args, h->geom, h->icb, h->ocb, h->G, h->grid, h->lds, s, mode);
@@ -298,15 +313,16 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
   a.rm0 = d.conv0_round_mode; a.rm1 = d.conv1_round_mode;
 
   bool want_mfma = mfma_eligible(d) && d.force_variant != DFX_VARIANT_GENERIC;
-  if (d.force_variant == DFX_VARIANT_MFMA_FUSED && !mfma_eligible(d)) {
+  if ((d.force_variant == DFX_VARIANT_MFMA_FUSED || d.force_variant == DFX_VARIANT_MFMA_CONV) && !mfma_eligible(d)) {
     delete h;
     return fail(DFX_ERR_UNSUPPORTED, "conv_create: shape not covered by the MFMA variant");
   }
   if (want_mfma && pick_geometry(d, h->geom, h->lds)) {
-    h->variant = DFX_VARIANT_MFMA_FUSED;
+    const bool fused = d.oc1x1 > 0;
+    h->variant = fused ? DFX_VARIANT_MFMA_FUSED : DFX_VARIANT_MFMA_CONV;
     h->icb = d.ic / 32; h->ocb = d.oc / 32;
     const int ncb = d.oc1x1 / 32;
-    h->G = (ncb % 4 == 0) ? 4 : (ncb % 2 == 0 ? 2 : 1);
+    h->G = fused ? ((ncb % 4 == 0) ? 4 : (ncb % 2 == 0 ? 2 : 1)) : h->ocb;
     {
       int dev = 0;
       hipDeviceProp_t prop;
@@ -341,8 +357,8 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
 #endif
     a.rows_per_unit = h->geom.th;
     a.units_per_image = h->geom.uy * h->geom.ux;
-    snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_mfma_fused_kernel<%d,%d,%d,%d>", h->icb,
-             h->ocb, h->G, d.dst_dt);
+    snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_mfma_fused_kernel<%d,%d,%d,%d%s>", h->icb,
+             h->ocb, h->G, d.dst_dt, fused ? "" : ",unfused");
     if (mfma_dispatch(h, nullptr, 1) != 0) {
       delete h;
       return fail(DFX_ERR_HIP, "conv_create: cannot raise dynamic LDS limit to %d bytes", h->lds);
@@ -394,7 +410,7 @@ int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei, const void *bia0, con
     s1[c] = scales1[d.conv1_nscales > 1 ? c : 0];
   }
 
-  if (h->variant == DFX_VARIANT_MFMA_FUSED) {
+  if (h->variant != DFX_VARIANT_GENERIC) {
     const int ICB = h->icb, OCB = h->ocb, G = h->G, NCB = OC1 / 32;
     // W0 fragments [r][tap][c][lane][16]: lane (rho = lane&31, hh = lane>>5), byte j
     //   = W0[oc = 32r + rho][ic = 32c + 16hh + j][tap]
@@ -403,7 +419,10 @@ int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei, const void *bia0, con
         for (int c = 0; c < ICB; ++c)
           for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 16; ++j) {
-              const int oc = 32 * r + (lane & 31), ic = 32 * c + 16 * (lane >> 5) + j;
+              // fused: A operand, row = oc 32r + rho.  unfused: B operand with the channel
+              // permutation of the store stage (G == OCB): column lam of block r = oc G*lam + r
+              const int oc = fused ? 32 * r + (lane & 31) : G * (lane & 31) + r;
+              const int ic = 32 * c + 16 * (lane >> 5) + j;
               p0[((((size_t)r * 9 + tap) * ICB + c) * 64 + lane) * 16 + j] =
                   wei[dfx_blocked_offset(oc, ic, tap / 3, tap % 3, IC, 3, 3)];
             }
@@ -436,7 +455,7 @@ int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei, const void *bia0, con
     // before vcvtps2dq (|acc| <= 255 * max(sum w+, -sum w-)); and comp + bias folds into
     // ONE exact f32 add: bias integer-valued, |comp + bias| < 2^24 and |acc + bias| < 2^24,
     // so float(acc) + float(bias) of the reference == float(raw) + float(comp + bias).
-    bool fast = d.conv0_round_mode == DFX_ROUND_NEAREST && d.conv1_round_mode == DFX_ROUND_NEAREST;
+    bool fast = d.conv0_round_mode == DFX_ROUND_NEAREST && (!fused || d.conv1_round_mode == DFX_ROUND_NEAREST);
     auto ok_channel = [](double amax, float comp, float bias, float scale) {
       if (!std::isfinite(bias) || !std::isfinite(scale)) return false;
       const double b = bias;
@@ -472,7 +491,7 @@ int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei, const void *bia0, con
     if (fused) memcpy(p1.data(), wei1, nw1);
   }
 
-  if (h->variant == DFX_VARIANT_MFMA_FUSED) {
+  if (h->variant != DFX_VARIANT_GENERIC) {
     // one buffer in LDS-image order: [W0 fragments | W1 fragments | constants]
     const size_t cbytes = round16(cst.size() * 4);
     if (!h->d_wei) HIP_TRY(hipMalloc(&h->d_wei, nw0 + nw1 + cbytes));
@@ -506,7 +525,7 @@ int dfx_conv_submit(dfx_conv_t *h, const void *src_dev, void *dst_dev, dfx_strea
   h->args.src = (const uint8_t *)src_dev;
   h->args.dst = dst_dev;
   int rc;
-  if (h->variant == DFX_VARIANT_MFMA_FUSED)
+  if (h->variant != DFX_VARIANT_GENERIC)
     rc = mfma_dispatch(h, (hipStream_t)s, 0);
   else
     rc = launch_conv_generic(h->args, (hipStream_t)s, nullptr, nullptr);
@@ -542,7 +561,7 @@ int dfx_conv_query(const dfx_conv_t *h, dfx_conv_info *info) {
   memset(info, 0, sizeof(*info));
   info->variant = h->variant;
   info->grid = h->grid; info->block = h->block; info->lds_bytes = h->lds;
-  info->rows_per_unit = h->variant == DFX_VARIANT_MFMA_FUSED ? h->geom.th : 0;
+  info->rows_per_unit = h->variant != DFX_VARIANT_GENERIC ? h->geom.th : 0;
   const uint64_t px = (uint64_t)d.bs * d.oh * d.ow;
   const uint64_t mac = px * ((uint64_t)d.oc * d.ic * d.kh * d.kw + (uint64_t)d.oc1x1 * d.oc);
   info->algorithmic_ops = 2 * mac;

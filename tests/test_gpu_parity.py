@@ -42,6 +42,21 @@ def test_fused_auto_variant(hip, oracle, case):
     hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), info.kernel_name.decode())
 
 
+UNFUSED_MFMA_CASES = ([C.unfused(c) for c in C.dtype_matrix(C.SMALL) + C.option_sweep(C.SMALL) + C.option_sweep(C.SMALL64)]
+                      + [C.unfused(C.CONFIG2), C.unfused(C.REF_SHAPES[2]), C.unfused(replace(C.CONFIG3_SMALL, dst_dt=C.U8)),
+                         C.unfused(replace(C.CONFIG3_SMALL, dst_dt=C.F32, relu0=False, per_channel0=True)),
+                         C.unfused(C.ConvCase("w96", 1, 64, 6, 96, 32, 0, dst_dt=C.S32, pad=(0, 1)))])
+
+
+@pytest.mark.parametrize("case", UNFUSED_MFMA_CASES, ids=lambda c: c.ident())
+def test_unfused_mfma_variant(hip, oracle, case):
+    """the unfused conv() overload on the int8-MFMA kernel (D0[px][oc] orientation)."""
+    data = C.generate(case)
+    got, info = hip.hip_conv(case, data)
+    assert info.variant == hip.dfa.VARIANT_MFMA_CONV, info.kernel_name
+    hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), info.kernel_name.decode())
+
+
 GENERIC_CASES = (C.dtype_matrix(C.SMALL) + C.option_sweep(C.SMALL)
                  + [C.unfused(c) for c in C.dtype_matrix(C.SMALL) + C.option_sweep(C.SMALL64)]
                  + [C.CONFIG2, C.REF_SHAPES[0],
