@@ -124,6 +124,10 @@ __device__ __forceinline__ float acc_to_f32(int raw, float comp, float bias) {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+#ifndef DFX_RING
+#define DFX_RING 4  // conv0 fragment ring depth (see the conv0 loop)
+#endif
+
 // The output is written once and never re-read by this kernel: non-temporal stores
 // keep it from displacing the input rows / weights in L2 and leave fewer dirty lines
 // to write back at the end of the kernel.
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
 
       DFX_STAMP(c2);
       // ---- conv0: 9 taps x ICB k-steps x OCB row blocks ----
-      // Explicit 4-deep fragment ring: the fragments of k-step s+3 are fetched right
+      // Explicit RD-deep fragment ring: the fragments of k-step s+RD-1 are fetched right
       // after the MFMAs of step s were issued, into the registers last read by the
       // MFMAs of step s-1.  An LDS load must never target a register that a just-issued
       // MFMA still has to read as A/B operand (see the note at the 1x1 stage); here at
@@ -435,7 +439,8 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
       for (int r = 0; r < OCB; ++r) acc0[r] = zero16;
       {
         constexpr int NS = 9 * ICB;  // k-steps
-        v4i fb[4], fw[4][OCB];
+        constexpr int RD = DFX_RING;  // ring slots; fragments are fetched RD-1 steps ahead
+        v4i fb[RD], fw[RD][OCB];
         auto fetch = [&](int st, int slot) {  // st, slot are compile-time after unrolling
           const int tap = st / ICB, c = st % ICB;
           const int P = Pb + (tap / 3) * LW + (tap % 3);
@@ -444,18 +449,17 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
           for (int r = 0; r < OCB; ++r)
             fw[slot][r] = *reinterpret_cast<const v4i *>(w0s + ((r * 9 + tap) * ICB + c) * 1024 + lane16);
         };
-        fetch(0, 0);
-        fetch(1, 1);
-        fetch(2, 2);
+#pragma unroll
+        for (int st = 0; st < RD - 1; ++st) fetch(st, st);
 #pragma unroll
         for (int st = 0; st < NS; ++st) {
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int r = 0; r < OCB; ++r)
-            acc0[r] = FUSED ? mfma_i8(fw[st & 3][r], fb[st & 3], acc0[r])   // D0[oc][px]
-                            : mfma_i8(fb[st & 3], fw[st & 3][r], acc0[r]);  // D0[px][oc]
+            acc0[r] = FUSED ? mfma_i8(fw[st % RD][r], fb[st % RD], acc0[r])   // D0[oc][px]
+                            : mfma_i8(fb[st % RD], fw[st % RD][r], acc0[r]);  // D0[px][oc]
           __builtin_amdgcn_sched_barrier(0);
-          if (st + 3 < NS) fetch(st + 3, (st + 3) & 3);
+          if (st + RD - 1 < NS) fetch(st + RD - 1, (st + RD - 1) % RD);
         }
       }
 
