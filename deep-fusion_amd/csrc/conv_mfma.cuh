@@ -384,6 +384,8 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
 #endif
   DFX_STAMP(t_loop);
   DFX_ACC(4, t_loop - t_entry);  // start-up: weights staging + barrier
+  int rot = 0;  // tile i of a unit goes to compute wave (rot + i) % MFMA_CW; rot advances by the
+               // unit's tile count, so units with fewer than MFMA_CW tiles keep every wave busy
   for (int k = 0;; ++k) {
     const int b = k & 1;
     const unsigned char *ins = team_tiles + (size_t)b * g.tile_stride;
@@ -403,7 +405,10 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
     const int tiles_per_row = (tw + 31) >> 5;
     const int ntiles = g.linear ? (npx + 31) >> 5 : th * tiles_per_row;
 
-    for (int t = cw; t < ntiles; t += MFMA_CW) {
+    int t0 = cw - rot;
+    if (t0 < 0) t0 += MFMA_CW;
+    rot = (rot + ntiles) % MFMA_CW;
+    for (int t = t0; t < ntiles; t += MFMA_CW) {
       // pixel of this lane (conv0 column) and the tile's output base (wave-uniform)
       int ty, tx, nvalid;
       size_t obase;  // dst pixel index of px_local == 0

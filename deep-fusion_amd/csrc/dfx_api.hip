@@ -214,9 +214,11 @@ static size_t round16(size_t v) { return (v + 15) & ~(size_t)15; }
 
 // Pick the unit decomposition of the MFMA variant: TH output rows x TW output
 // columns per unit, either full-width rows (linear pixel numbering) or TW a
-// multiple of 32.  Scored by how well a unit's 32-pixel tiles fill the 7 compute
-// waves, how little halo it re-reads, and whether the loader wave can hold the
-// whole halo tile in registers.  false if nothing fits LDS.
+// multiple of 32.  Scored by how full a unit's 32-pixel tiles are (tiles rotate over
+// the compute waves, so the tile count per unit need not match the wave count), how
+// little halo it re-reads, whether the loader wave can hold the whole halo tile in
+// registers, and -- for HBM-bound outputs -- how fine the dynamic hand-out is.
+// false if nothing fits LDS.
 static bool pick_geometry(const dfx_conv_desc &d, MfmaGeom &g, int &lds) {
   const int ICB = d.ic / 32, OCB = d.oc / 32, NCB = d.oc1x1 / 32;
   const size_t fixed = (size_t)OCB * 9 * ICB * 1024 + (size_t)NCB * OCB * 1024 +
@@ -229,6 +231,8 @@ static bool pick_geometry(const dfx_conv_desc &d, MfmaGeom &g, int &lds) {
   if (th_par < 1) th_par = 1;
   if (th_par < 2 && (long long)d.bs * d.oh / 2 >= 512) th_par = 2;
   if (th_par > 16) th_par = 16;
+  if (const char *e = getenv("DFX_MAX_TH")) th_par = std::max(1, std::min(th_par, atoi(e)));  // tuning aid
+  const bool hbm_bound_dst = d.dst_dt == DFX_S32 || d.dst_dt == DFX_F32;
   double best = -1.0;
   for (int mode = 0; mode < 2; ++mode)
     for (int tw = (mode == 0 ? d.ow : 32); tw <= (mode == 0 ? d.ow : std::min(d.ow, 256)); tw += 32) {
@@ -238,15 +242,21 @@ static bool pick_geometry(const dfx_conv_desc &d, MfmaGeom &g, int &lds) {
         if (tile > tile_max) break;
         const int npx = th * tw;
         const int ntiles = mode == 0 ? (npx + 31) / 32 : th * (tw / 32);
-        const int rounds = (ntiles + MFMA_CW - 1) / MFMA_CW;
         const double px_eff = (double)npx / (32.0 * ntiles);
-        const double wave_eff = (double)ntiles / (MFMA_CW * rounds);
         const double halo_eff = (double)npx / ((th + 2.0) * (tw + 2.0));
         // edge units are partial: fraction of the covered area that is real output
         const double cover = ((double)d.oh * d.ow) /
                              ((double)((d.oh + th - 1) / th * th) * ((d.ow + tw - 1) / tw * tw));
         const bool oversize = (tile - 16) / 16 > (size_t)64 * MFMA_LC;
-        const double score = px_eff * wave_eff * cover * (0.75 + 0.25 * halo_eff) * (oversize ? 0.9 : 1.0);
+        double score = px_eff * cover * (0.75 + 0.25 * halo_eff) * (oversize ? 0.9 : 1.0);
+        // 4-byte outputs are HBM-write bound and the XCDs drain at different rates: the
+        // dynamic tail then dominates, so prefer >= ~7 units per team (finer hand-out)
+        // over perfectly filled waves (measured: 4 -> 2 rows per unit = -5 % at config 3)
+        if (hbm_bound_dst) {
+          const long long units = (long long)d.bs * ((d.oh + th - 1) / th) * ((d.ow + tw - 1) / tw);
+          if (th > 1 && units < 6LL * 2 * 256) score *= 0.5;
+          if (mode == 0) score *= 1.08;  // full-width units measured best here (2x56: 86 us, 4x32: 89 us, 4x56: 93 us)
+        }
         if (score > best) {
           best = score;
           g.th = th; g.tw = tw; g.linear = mode == 0;
@@ -254,6 +264,13 @@ static bool pick_geometry(const dfx_conv_desc &d, MfmaGeom &g, int &lds) {
       }
     }
   if (best < 0) return false;
+  if (const char *e = getenv("DFX_FORCE_GEOM")) {  // tuning aid: "th,tw" (must fit LDS)
+    int fth = 0, ftw = 0;
+    if (sscanf(e, "%d,%d", &fth, &ftw) == 2 && fth >= 1 && (ftw == d.ow || (ftw % 32 == 0 && ftw < d.ow)) &&
+        (size_t)(fth + 2) * (ftw + 2) * d.ic + 16 <= tile_max) {
+      g.th = fth; g.tw = ftw; g.linear = ftw == d.ow;
+    }
+  }
   g.uy = (d.oh + g.th - 1) / g.th;
   g.ux = (d.ow + g.tw - 1) / g.tw;
   g.total_units = d.bs * g.uy * g.ux;
@@ -344,8 +361,8 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     h->geom.fast = 0;
     {
       const int teams = h->grid * MFMA_TEAMS;
-      h->geom.static_rounds = std::max(0, h->geom.total_units / teams - 1);
-      if (const char *e = getenv("DFX_STATIC_ROUNDS")) h->geom.static_rounds = std::min(h->geom.static_rounds, atoi(e));  // tuning aid
+      h->geom.static_rounds = std::min(3, std::max(0, h->geom.total_units / teams - 1));
+      if (const char *e = getenv("DFX_STATIC_ROUNDS")) h->geom.static_rounds = std::min(std::max(0, h->geom.total_units / teams - 1), atoi(e));  // tuning aid
     }
 #ifdef DFX_STAMPS
     if (hipMalloc((void **)&h->d_prof, (size_t)h->grid * 256 * 8) != hipSuccess ||
