@@ -316,13 +316,13 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
       return v;
     };
 
-    int wr_off[MFMA_LC];
-#pragma unroll
-    for (int i = 0; i < MFMA_LC; ++i) wr_off[i] = chunk_lds_off(lane + 64 * i);
     int cur = __builtin_amdgcn_readfirstlane(unit_at(0));
     int nxt_v = unit_at(1);
     int jn = 2;
     if (cur < g.total_units) DFX_PREFETCH(cur);  // first tile's loads fly during the weight copy
+    int wr_off[MFMA_LC];  // (computed while those loads are in flight)
+#pragma unroll
+    for (int i = 0; i < MFMA_LC; ++i) wr_off[i] = chunk_lds_off(lane + 64 * i);
     __syncthreads();  // the only workgroup barrier: weights + control block are in LDS
 
     for (int k = 0;; ++k) {
