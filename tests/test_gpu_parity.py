@@ -225,3 +225,15 @@ def test_repeated_submits_rearm_queue(hip, oracle):
         for o in outs:
             hip.assert_bit_equal(o.cpu().numpy(), ref, "repeat " + case.name)
         op.close()
+
+
+@pytest.mark.parametrize("geom", ["1,56", "2,56", "3,56", "4,56", "5,56", "4,32", "2,32", "7,32"])
+def test_unit_geometries_and_tile_rotation(hip, oracle, geom, monkeypatch):
+    """every unit decomposition the host may pick (full-width linear units, 32-multiple
+    column units, tile counts that do not divide the 7 compute waves) gives the same bytes."""
+    monkeypatch.setenv("DFX_FORCE_GEOM", geom)
+    for case in (replace(C.CONFIG3_SMALL, bs=3), replace(C.CONFIG3_SMALL, bs=3, dst_dt=C.U8, wide=True)):
+        data = C.generate(case)
+        got, info = hip.hip_conv(case, data)
+        assert info.variant == hip.dfa.VARIANT_MFMA_FUSED and info.rows_per_unit == int(geom.split(",")[0])
+        hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), "geom " + geom)
