@@ -55,8 +55,10 @@ def workloads():
     }
 
 
-def cpu_baseline(case, data, threads, budget_s=12.0):
-    """Oracle port timed on the host cores on a bounded sample of the workload."""
+def cpu_baseline(case, data, threads, gpu_out, budget_s=12.0):
+    """Oracle port timed on the host cores on a bounded sample of the workload.  This leg
+    is the only place bench.py touches oracle/: it also uses the sample's oracle output as
+    the checker of what the timed GPU path wrote (never as something measured or shipped)."""
     from dataclasses import replace
     from oracle import oracle as orc
     import hipref
@@ -65,7 +67,8 @@ def cpu_baseline(case, data, threads, budget_s=12.0):
     n = min(case.bs, 32 if impl == "avx512" else 4)
     sub = dict(data, src=data["src"][:n])
     c = replace(case, bs=n)
-    hipref.oracle_conv(orc, c, sub, impl)                     # warm-up
+    ref = hipref.oracle_conv(orc, c, sub, impl)               # warm-up + checker
+    hipref.assert_bit_equal(gpu_out[:n], ref, "bench output vs oracle")
     t0 = time.perf_counter()
     reps = 0
     while True:
@@ -75,7 +78,7 @@ def cpu_baseline(case, data, threads, budget_s=12.0):
         if el > budget_s or reps >= 100:
             break
     return {"value": round(n * reps / el, 2), "unit": "images/sec", "cores": orc.num_threads(),
-            "kind": "port",
+            "kind": "port", "gpu_output_matches_oracle": True,
             "sample": "%d images x %d reps of the same workload, oracle impl=%s (%s)" % (
                 n, reps, impl,
                 "AVX-512 VNNI intrinsics mirroring the reference JIT, OpenMP over (n,oh)"
@@ -170,14 +173,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, kern_ms = float(tt[0]), float(tt[1])
 
-    # sanity: the timed path produced the oracle's bytes (first image, rank 0)
     extra = {}
-    if rank == 0:
-        from oracle import oracle as orc
-        one = dict(data, src=data["src"][:1])
-        ref = hipref.oracle_conv(orc, replace(case, bs=1), one)
-        hipref.assert_bit_equal(dsts[0][:1].cpu().numpy(), ref, "bench output vs oracle")
-
     # configs[3]: op_concat + RCCL all-gather, measured outside the timed region
     if world > 1 and dist.get_backend() == "nccl":
         try:
@@ -217,7 +213,8 @@ def main():
         }
         out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(case, data, args.cpu_threads or min(os.cpu_count() or 1, 16))
+            out["cpu_baseline"] = cpu_baseline(case, data, args.cpu_threads or min(os.cpu_count() or 1, 16),
+                                               dsts[0][:32].cpu().numpy())
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
