@@ -52,6 +52,15 @@ def workloads():
                 "BASELINE configs[4]: N=64 224x224 64->64->128 u8xs8"),
         "bringup": (C.ConvCase("bringup", 1, 32, 28, 28, 32, 64, dst_dt=C.U8),
                     "BASELINE configs[1]: N=1 28x28 32->32->64 u8xs8"),
+        # SURVEY 8(f) rank 3 (general shapes, streamed-weight MFMA kernel): deeper ResNet-50 stages
+        "res3": (C.ConvCase("res3", 128, 128, 28, 28, 128, 512, dst_dt=C.U8),
+                 "ResNet-50 res3-style block: N=128 28x28 128->128->512 u8xs8"),
+        "res4": (C.ConvCase("res4", 128, 256, 14, 14, 256, 1024, dst_dt=C.U8),
+                 "ResNet-50 res4-style block: N=128 14x14 256->256->1024 u8xs8"),
+        "res5": (C.ConvCase("res5", 128, 512, 7, 7, 512, 2048, dst_dt=C.U8),
+                 "ResNet-50 res5-style block: N=128 7x7 512->512->2048 u8xs8"),
+        "res3s2": (C.ConvCase("res3s2", 128, 128, 56, 56, 128, 512, stride=(2, 2), dst_dt=C.U8),
+                   "ResNet-50 res3a-style stride-2 block: N=128 56x56 128->128->512 s2 u8xs8"),
     }
 
 
@@ -103,7 +112,7 @@ def main():
     ap.add_argument("--workload", default="res2a")
     ap.add_argument("--dst", default=None, help="override dst dtype: u8|s8|s32|f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--variant", type=int, default=-1, help="-1 auto, 0 generic, 1 mfma")
+    ap.add_argument("--variant", type=int, default=-1, help="-1 auto, 0 generic, 1/2 resident-weight mfma, 3 streamed-weight mfma")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="OpenMP threads of the CPU baseline (default: min(host cpus, 16) = one GPU's CPU share)")
     args = ap.parse_args()

@@ -13,7 +13,7 @@ _HEADER = os.path.join(_ROOT, "include", "dfx.h")
 
 DFX_UNDEF, DFX_F32, DFX_S32, DFX_S8, DFX_U8 = 0, 1, 2, 3, 4
 ROUND_NEAREST, ROUND_DOWN = 0, 1
-VARIANT_GENERIC, VARIANT_MFMA_FUSED, VARIANT_MFMA_CONV = 0, 1, 2
+VARIANT_GENERIC, VARIANT_MFMA_FUSED, VARIANT_MFMA_CONV, VARIANT_MFMA_STREAM = 0, 1, 2, 3
 _NP = {DFX_F32: np.float32, DFX_S32: np.int32, DFX_S8: np.int8, DFX_U8: np.uint8}
 _DT = {np.dtype(np.float32): DFX_F32, np.dtype(np.int32): DFX_S32,
        np.dtype(np.int8): DFX_S8, np.dtype(np.uint8): DFX_U8}

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "conv_mfma.cuh"
+#include "conv_stream.cuh"
 #include "dfx_device.cuh"
 
 namespace dfx {
@@ -34,6 +35,14 @@ DFX_DECL(u8);
 #undef DFX_DECL
 #define DFX_DECL(n) \
   int launch_conv_mfma_##n##_unfused(const ConvArgs &, const MfmaGeom &, int, int, int, int, hipStream_t, int)
+DFX_DECL(f32);
+DFX_DECL(s32);
+DFX_DECL(s8);
+DFX_DECL(u8);
+#undef DFX_DECL
+
+#define DFX_DECL(n) \
+  int launch_conv_stream_##n(const ConvArgs &, const StreamGeom &, int, int, int, int, int, hipStream_t, int)
 DFX_DECL(f32);
 DFX_DECL(s32);
 DFX_DECL(s8);
@@ -70,6 +79,8 @@ struct dfx_conv {
   int variant;
   ConvArgs args;
   MfmaGeom geom;
+  StreamGeom sgeom;  // DFX_VARIANT_MFMA_STREAM
+  int occ;           // stream variant: conv0 output blocks per chunk
   int icb, ocb, G, grid, block, lds;
   void *d_wei, *d_wei1, *d_consts;
   int *d_queue;  // MFMA variant: {next unit, finished workgroups}
@@ -287,7 +298,79 @@ static bool mfma_eligible(const dfx_conv_desc &d) {  // fused or unfused (oc1x1 
          (d.ic == 32 || d.ic == 64) && (d.oc == 32 || d.oc == 64) && d.oc1x1 % 32 == 0;
 }
 
+// ---- streamed-weight variant (conv_stream.cuh) ----
+// blocks per chunk / group: the largest of {4,2,1} that pads the block count by <= 1/3
+static int pick_blocking(int nblocks) {
+  for (int x : {4, 2, 1}) {
+    const int padded = (nblocks + x - 1) / x * x;
+    if (3 * padded <= 4 * nblocks) return x;
+  }
+  return 1;
+}
+
+static bool pick_stream_geometry(const dfx_conv_desc &d, int OCC, int G, StreamGeom &g, int &lds) {
+  const bool fused = d.oc1x1 > 0;
+  const int icb = (d.ic + 31) / 32, ocb_real = (d.oc + 31) / 32;
+  g.icb = icb;
+  g.n_icc = (icb + 1) / 2;
+  g.n_occ = (ocb_real + OCC - 1) / OCC;
+  g.ocb = g.n_occ * OCC;
+  g.n_g1 = fused ? ((d.oc1x1 + 31) / 32 + G - 1) / G : 0;
+  g.ks2 = (g.ocb + 1) / 2;
+  g.mid_stride = 32 * g.ocb + 16;
+  int s0 = 0;
+  for (int c = 0; c < g.n_icc; ++c) s0 += (d.kh * d.kw * std::min(2, icb - 2 * c) + 1) / 2;
+  g.s0_steps = s0 * g.n_occ;
+  const int WB = fused ? std::max(OCC, G) : OCC;
+  const size_t fixed = (size_t)2 * 2 * WB * 1024 + 4 * ST_M + (fused ? (size_t)ST_M * g.mid_stride : 0);
+  const size_t lds_max = 163840;
+  // index ranges the kernel keeps in 32 bits / packed fields
+  if ((long long)d.bs * d.oh * d.ow >= (1LL << 31) || (long long)d.ih * d.iw * d.ic * ST_M >= (1LL << 31)) return false;
+  double best = -1.0;
+  auto consider = [&](int ni, int thv, int twv) {
+    const int lh = (thv - 1) * d.sh + d.kh, lw = (twv - 1) * d.sw + d.kw;
+    if (lh >= 1024 || lw >= 1024) return;
+    const long long npos = (long long)ni * lh * lw;
+    if (fixed + (size_t)npos * 64 > lds_max) return;
+    const double groups = (double)((d.bs + ni - 1) / ni);
+    const double units = groups * ((d.oh + thv - 1) / thv) * ((d.ow + twv - 1) / twv);
+    const double util = (double)d.bs * d.oh * d.ow / (units * ST_M);        // filled pixel slots
+    const double halo = (double)thv * d.sh * twv * d.sw / ((double)lh * lw);  // input re-read
+    const double score = util * (0.8 + 0.2 * std::min(1.0, halo));
+    if (score > best) {
+      best = score;
+      g.ni = ni; g.thv = thv; g.twv = twv; g.lh = lh; g.lw = lw; g.npos = (int)npos;
+    }
+  };
+  if (d.oh * d.ow <= ST_M) {
+    for (int ni = std::min(d.bs, ST_M / (d.oh * d.ow)); ni >= 1; --ni) consider(ni, d.oh, d.ow);
+  } else {
+    for (int twv = 1; twv <= std::min(d.ow, ST_M); ++twv) consider(1, std::min(d.oh, ST_M / twv), twv);
+  }
+  if (best < 0) return false;
+  g.uy = (d.oh + g.thv - 1) / g.thv;
+  g.ux = (d.ow + g.twv - 1) / g.twv;
+  g.total_units = (d.bs + g.ni - 1) / g.ni * g.uy * g.ux;
+  g.off_tile = 2 * 2 * WB * 1024;
+  g.off_pxoff = (int)round16((size_t)g.off_tile + (size_t)g.npos * 64);
+  g.off_mid = g.off_pxoff + 4 * ST_M;
+  lds = g.off_mid + (fused ? ST_M * g.mid_stride : 0);
+  return true;
+}
+
+static int stream_dispatch(dfx_conv *h, hipStream_t s, int mode) {
+  const int fused = h->d.oc1x1 > 0;
+  switch (h->d.dst_dt) {
+    case DFX_F32: return launch_conv_stream_f32(h->args, h->sgeom, h->occ, h->G, fused, h->grid, h->lds, s, mode);
+    case DFX_S32: return launch_conv_stream_s32(h->args, h->sgeom, h->occ, h->G, fused, h->grid, h->lds, s, mode);
+    case DFX_S8: return launch_conv_stream_s8(h->args, h->sgeom, h->occ, h->G, fused, h->grid, h->lds, s, mode);
+    case DFX_U8: return launch_conv_stream_u8(h->args, h->sgeom, h->occ, h->G, fused, h->grid, h->lds, s, mode);
+  }
+  return -1;
+}
+
 static int mfma_dispatch(dfx_conv *h, hipStream_t s, int mode) {
+  if (h->variant == DFX_VARIANT_MFMA_STREAM) return stream_dispatch(h, s, mode);
   if (h->variant == DFX_VARIANT_MFMA_CONV) {
     switch (h->d.dst_dt) {
       case DFX_F32: return launch_conv_mfma_f32_unfused(h->args, h->geom, h->icb, h->ocb, h->grid, h->lds, s, mode);
@@ -329,12 +412,44 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
   a.oc1 = d.oc1x1; a.dst_dt = d.dst_dt; a.relu0 = d.conv0_relu; a.relu1 = d.conv1_relu;
   a.rm0 = d.conv0_round_mode; a.rm1 = d.conv1_round_mode;
 
-  bool want_mfma = mfma_eligible(d) && d.force_variant != DFX_VARIANT_GENERIC;
+  bool want_mfma = mfma_eligible(d) && d.force_variant != DFX_VARIANT_GENERIC &&
+                   d.force_variant != DFX_VARIANT_MFMA_STREAM;
   if ((d.force_variant == DFX_VARIANT_MFMA_FUSED || d.force_variant == DFX_VARIANT_MFMA_CONV) && !mfma_eligible(d)) {
     delete h;
     return fail(DFX_ERR_UNSUPPORTED, "conv_create: shape not covered by the MFMA variant");
   }
-  if (want_mfma && pick_geometry(d, h->geom, h->lds)) {
+  const bool want_stream = !want_mfma && d.force_variant != DFX_VARIANT_GENERIC;
+  bool stream_ok = false;
+  if (want_stream) {
+    h->occ = pick_blocking((d.oc + 31) / 32);
+    h->G = d.oc1x1 ? pick_blocking((d.oc1x1 + 31) / 32) : h->occ;
+    stream_ok = pick_stream_geometry(d, h->occ, h->G, h->sgeom, h->lds);
+    if (!stream_ok && d.force_variant == DFX_VARIANT_MFMA_STREAM) {
+      delete h;
+      return fail(DFX_ERR_UNSUPPORTED, "conv_create: shape does not fit the streamed MFMA variant");
+    }
+  }
+  if (stream_ok) {
+    h->variant = DFX_VARIANT_MFMA_STREAM;
+    h->block = ST_THREADS;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+      delete h;
+      return fail(DFX_ERR_HIP, "conv_create: cannot query the device");
+    }
+    if (mfma_dispatch(h, nullptr, 1) != 0) {
+      delete h;
+      return fail(DFX_ERR_HIP, "conv_create: cannot raise dynamic LDS limit to %d bytes", h->lds);
+    }
+    int per_cu = mfma_dispatch(h, nullptr, 2);
+    if (per_cu < 1) per_cu = 1;
+    h->grid = std::min(h->sgeom.total_units, prop.multiProcessorCount * per_cu);
+    a.rows_per_unit = h->sgeom.thv;
+    a.units_per_image = h->sgeom.uy * h->sgeom.ux;
+    snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_stream_kernel<%d,%d,%d,%s>", h->occ, h->G, d.dst_dt,
+             d.oc1x1 ? "fused" : "unfused");
+  } else if (want_mfma && pick_geometry(d, h->geom, h->lds)) {
     const bool fused = d.oc1x1 > 0;
     h->variant = fused ? DFX_VARIANT_MFMA_FUSED : DFX_VARIANT_MFMA_CONV;
     h->icb = d.ic / 32; h->ocb = d.oc / 32;
@@ -401,6 +516,82 @@ static float bias_to_f32(const void *b, int dt, int c) {
   return 0.0f;
 }
 
+// Packs weights for conv_stream.cuh: ONE device buffer
+//   [conv0 steps | conv1 steps | consts], a step = 2 k-blocks x (OCC | G) fragments of 1 KB,
+// in the exact order the kernel walks them (oc chunk, ic chunk, step; 1x1 group, step).
+static int set_weights_stream(dfx_conv_t *h, const int8_t *wei, const void *bia0, const float *scales0,
+                              const int8_t *wei1, const void *bia1, const float *scales1) {
+  const dfx_conv_desc &d = h->d;
+  const StreamGeom &g = h->sgeom;
+  const bool fused = d.oc1x1 > 0;
+  const int OCC = h->occ, G = h->G, OC = d.oc, IC = d.ic, OC1 = d.oc1x1;
+  const int OCP = 32 * g.ocb, OC1P = fused ? 32 * G * g.n_g1 : 0;
+  const size_t n0 = (size_t)g.s0_steps * 2 * OCC * 1024;
+  const size_t n1 = fused ? (size_t)g.n_g1 * g.ks2 * 2 * G * 1024 : 0;
+  std::vector<int8_t> pk(n0 + n1, 0);
+  const int ntap = d.kh * d.kw;
+  size_t o = 0;
+  for (int occ = 0; occ < g.n_occ; ++occ)
+    for (int icc = 0; icc < g.n_icc; ++icc) {
+      const int kbn = std::min(2, g.icb - 2 * icc), ns = ntap * kbn;
+      for (int s2 = 0; s2 < (ns + 1) / 2; ++s2)
+        for (int j = 0; j < 2; ++j)
+          for (int r = 0; r < OCC; ++r)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int b = 0; b < 16; ++b, ++o) {
+                const int s = 2 * s2 + j;
+                if (s >= ns) continue;  // padding k-block: zero weights
+                const int tap = s / kbn, icbl = s % kbn;
+                // fused: A operand, row = channel 32*(occ*OCC + r) + rho.  unfused: B operand with
+                // the store stage's channel permutation: column lam of block r = 32*OCC*occ + OCC*lam + r
+                const int oc = fused ? 32 * (occ * OCC + r) + (lane & 31) : 32 * OCC * occ + OCC * (lane & 31) + r;
+                const int ic = 64 * icc + 32 * icbl + 16 * (lane >> 5) + b;
+                if (oc < OC && ic < IC) pk[o] = wei[dfx_blocked_offset(oc, ic, tap / d.kw, tap % d.kw, IC, d.kh, d.kw)];
+              }
+    }
+  if (o != n0) return fail(DFX_ERR_HIP, "internal: conv0 pack size mismatch");
+  for (int g1 = 0; g1 < g.n_g1; ++g1)
+    for (int s2 = 0; s2 < g.ks2; ++s2)
+      for (int j = 0; j < 2; ++j)
+        for (int cc = 0; cc < G; ++cc)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int b = 0; b < 16; ++b, ++o) {
+              const int blk = 2 * s2 + j;
+              if (blk >= g.ocb) continue;
+              const int oc1 = 32 * G * g1 + G * (lane & 31) + cc;
+              const int oc = 32 * blk + 8 * (b >> 2) + 4 * (lane >> 5) + (b & 3);  // mid's k order
+              if (oc1 < OC1 && oc < OC) pk[o] = wei1[dfx_blocked_offset(oc1, oc, 0, 0, OC, 1, 1)];
+            }
+  // consts: comp0 (s32) bias0 scale0 [OCP each] comp1 (s32) bias1 scale1 [OC1P each]; padding
+  // channels are all-zero (their intermediate is 0 and meets zero 1x1 weights)
+  std::vector<int32_t> cst((size_t)3 * (OCP + OC1P), 0);
+  auto put_f = [&](size_t idx, float v) { memcpy(&cst[idx], &v, 4); };
+  for (int c = 0; c < OC; ++c) {
+    int32_t sum = 0;
+    for (int ic = 0; ic < IC; ++ic)
+      for (int tap = 0; tap < ntap; ++tap) sum += wei[dfx_blocked_offset(c, ic, tap / d.kw, tap % d.kw, IC, d.kh, d.kw)];
+    cst[c] = 128 * sum;
+    put_f((size_t)OCP + c, d.bia0_dt == DFX_UNDEF ? 0.0f : bias_to_f32(bia0, d.bia0_dt, c));
+    put_f((size_t)2 * OCP + c, scales0[d.conv0_nscales > 1 ? c : 0]);
+  }
+  for (int c = 0; c < OC1; ++c) {
+    int32_t sum = 0;
+    for (int oc = 0; oc < OC; ++oc) sum += wei1[dfx_blocked_offset(c, oc, 0, 0, OC, 1, 1)];
+    cst[(size_t)3 * OCP + c] = 128 * sum;
+    put_f((size_t)3 * OCP + OC1P + c, d.bia1_dt == DFX_UNDEF ? 0.0f : bias_to_f32(bia1, d.bia1_dt, c));
+    put_f((size_t)3 * OCP + 2 * OC1P + c, scales1[d.conv1_nscales > 1 ? c : 0]);
+  }
+  if (!h->d_wei) HIP_TRY(hipMalloc(&h->d_wei, pk.size() + cst.size() * 4));
+  char *base = (char *)h->d_wei;
+  HIP_TRY(hipMemcpy(base, pk.data(), pk.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(base + pk.size(), cst.data(), cst.size() * 4, hipMemcpyHostToDevice));
+  h->args.wei = (const int8_t *)base;
+  h->args.wei1 = (const int8_t *)(base + n0);
+  h->args.consts = (const float *)(base + pk.size());
+  h->weights_set = true;
+  return DFX_OK;
+}
+
 int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei, const void *bia0, const float *scales0,
                          const int8_t *wei1, const void *bia1, const float *scales1) {
   if (!h || !wei || !scales0) return fail(DFX_ERR_INVALID, "set_weights: null argument");
@@ -426,6 +617,8 @@ int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei, const void *bia0, con
     b1[c] = d.bia1_dt == DFX_UNDEF ? 0.0f : bias_to_f32(bia1, d.bia1_dt, c);
     s1[c] = scales1[d.conv1_nscales > 1 ? c : 0];
   }
+
+  if (h->variant == DFX_VARIANT_MFMA_STREAM) return set_weights_stream(h, wei, bia0, scales0, wei1, bia1, scales1);
 
   if (h->variant != DFX_VARIANT_GENERIC) {
     const int ICB = h->icb, OCB = h->ocb, G = h->G, NCB = OC1 / 32;
@@ -578,7 +771,7 @@ int dfx_conv_query(const dfx_conv_t *h, dfx_conv_info *info) {
   memset(info, 0, sizeof(*info));
   info->variant = h->variant;
   info->grid = h->grid; info->block = h->block; info->lds_bytes = h->lds;
-  info->rows_per_unit = h->variant != DFX_VARIANT_GENERIC ? h->geom.th : 0;
+  info->rows_per_unit = h->args.rows_per_unit;
   const uint64_t px = (uint64_t)d.bs * d.oh * d.ow;
   const uint64_t mac = px * ((uint64_t)d.oc * d.ic * d.kh * d.kw + (uint64_t)d.oc1x1 * d.oc);
   info->algorithmic_ops = 2 * mac;

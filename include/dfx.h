@@ -51,7 +51,8 @@ enum { DFX_ROUND_NEAREST = 0, DFX_ROUND_DOWN = 1 };
 enum {
   DFX_VARIANT_GENERIC = 0,    /* any shape the reference's init_conf accepts */
   DFX_VARIANT_MFMA_FUSED = 1, /* int8-MFMA implicit GEMM, 3x3 s1 + fused 1x1 */
-  DFX_VARIANT_MFMA_CONV = 2   /* int8-MFMA implicit GEMM, unfused 3x3 s1 conv */
+  DFX_VARIANT_MFMA_CONV = 2,  /* int8-MFMA implicit GEMM, unfused 3x3 s1 conv */
+  DFX_VARIANT_MFMA_STREAM = 3 /* int8-MFMA, streamed weights: any kernel/stride/channel count */
 };
 
 /* Create-time descriptor.  Mirrors the shape/dtype/flag fields of

@@ -74,6 +74,49 @@ def test_generic_variant(hip, oracle, case):
     hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), info.kernel_name.decode())
 
 
+# streamed-weight MFMA variant (conv_stream.cuh): general shapes -- SURVEY.md 8(f) rank 3
+STREAM_SHAPES = [
+    C.ConvCase("s2", 1, 16, 11, 9, 48, 80, stride=(2, 2)),
+    C.ConvCase("s2b", 3, 64, 15, 17, 64, 128, stride=(2, 2), dst_dt=C.S32),
+    C.ConvCase("s21", 2, 32, 12, 9, 32, 32, stride=(2, 1), pad=(0, 1), dst_dt=C.S8, relu1=False),
+    C.ConvCase("k5", 1, 16, 9, 9, 16, 16, k=(5, 5), pad=(2, 2)),
+    C.ConvCase("k7s2", 2, 16, 23, 21, 64, 64, k=(7, 7), stride=(2, 2), pad=(3, 3), dst_dt=C.S32),
+    C.ConvCase("k1", 2, 32, 5, 5, 32, 0, k=(1, 1), pad=(0, 0), dst_dt=C.S32),
+    C.ConvCase("k1f", 4, 48, 6, 5, 80, 48, k=(1, 1), pad=(0, 0), dst_dt=C.F32, relu1=False),
+    C.ConvCase("k13", 1, 32, 8, 10, 32, 64, k=(1, 3), pad=(0, 1), dst_dt=C.S32),
+    C.ConvCase("k31", 1, 32, 8, 10, 48, 0, k=(3, 1), pad=(1, 0), dst_dt=C.S8, relu0=False),
+    C.ConvCase("ic128", 1, 128, 6, 6, 80, 48, dst_dt=C.S32, wide=True),
+    C.ConvCase("ic80", 2, 80, 7, 7, 96, 160, dst_dt=C.U8, wide=True),
+    C.ConvCase("res3", 2, 128, 14, 14, 128, 512, dst_dt=C.S32),
+    C.ConvCase("res3w", 1, 128, 9, 20, 128, 256, dst_dt=C.U8, wide=True, per_channel0=True, per_channel1=True),
+    C.ConvCase("ic256", 1, 256, 7, 7, 256, 0, dst_dt=C.S32, wide=True, relu0=False),
+    C.ConvCase("oc320", 5, 64, 7, 7, 320, 112, dst_dt=C.F32, rm0=1),
+    C.ConvCase("img3", 7, 32, 3, 3, 32, 32, dst_dt=C.S32),
+    C.ConvCase("one", 1, 16, 3, 3, 16, 16, pad=(0, 0)),
+    C.ConvCase("w200", 1, 32, 3, 200, 32, 32, dst_dt=C.S32),
+    C.ConvCase("w131", 2, 16, 5, 131, 16, 0, dst_dt=C.U8, pad=(1, 0)),
+]
+STREAM_CASES = (STREAM_SHAPES + C.dtype_matrix(C.SMALL) + C.option_sweep(C.SMALL) + C.option_sweep(C.SMALL64)
+                + [C.unfused(c) for c in C.dtype_matrix(C.SMALL) + C.option_sweep(C.SMALL64)]
+                + [C.CONFIG2, C.CONFIG3_SMALL, C.unfused(C.REF_SHAPES[2])])
+
+
+@pytest.mark.parametrize("case", STREAM_CASES, ids=lambda c: c.ident())
+def test_stream_variant(hip, oracle, case):
+    data = C.generate(case)
+    got, info = hip.hip_conv(case, data, force_variant=hip.dfa.VARIANT_MFMA_STREAM)
+    assert info.variant == hip.dfa.VARIANT_MFMA_STREAM, info.kernel_name
+    hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), info.kernel_name.decode())
+
+
+def test_auto_variant_prefers_mfma(hip):
+    """shapes outside the resident-weight kernel go to the streamed MFMA kernel, not the scalar one."""
+    for case in STREAM_SHAPES[:4]:
+        op = hip.make_conv(case, C.generate(case))
+        assert op.info().variant == hip.dfa.VARIANT_MFMA_STREAM
+        op.close()
+
+
 def test_host_buffer_path(hip, oracle):
     """drop-in semantics of op::submit(): host pointers in, host pointers out."""
     for case in (C.CONFIG2, C.unfused(C.SMALL)):
