@@ -589,9 +589,9 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
         if (fast) { if (nvalid == 32) emit(T{}, F{}); else emit(T{}, T{}); }
         else      { if (nvalid == 32) emit(F{}, F{}); else emit(F{}, T{}); }
       }
-      }  // FUSED
       DFX_STAMP(c5);
       DFX_ACC(3, c5 - c4);  // conv1 + requant 1 + stores
+      }  // FUSED
       DFX_ACC(6, 1);
     }
     DFX_STAMP(c6);

@@ -6,15 +6,20 @@
 // admits (/root/reference/src/jit_conv_kernel.cc:512-673: ic, oc, oc1x1 multiples of 16,
 // any kernel size / stride / padding; multi-chunk accumulation :193-216, :27-48):
 //
-//  * A workgroup of 4 waves owns a UNIT of up to 128 output pixels: a th x tw patch of
-//    one image or, for small images, several whole images.  Wave w owns the 32 pixel
-//    slots 32w .. 32w+31 for both contractions.
+//  * A workgroup of 4 waves owns a UNIT of up to 128 * PXB output pixels: a th x tw patch
+//    of one image or, for small images, several whole images.  Wave w owns PXB blocks of
+//    32 pixel slots for both contractions; with PXB = 2 every weight fragment read from
+//    LDS feeds two MFMAs (the kernel is LDS-bandwidth bound at PXB = 1: 1.25 KB of
+//    fragments per MFMA against 128 B/clk/CU), at the price of twice the intermediate.
 //  * K is walked in STEPS of two 32-deep MFMA k-blocks.  The packed weight fragments
 //    of a step (2 x OCC or 2 x G KB, laid out by the host in exactly the order the
 //    kernel walks them) travel global -> registers -> LDS, double buffered: the loads
 //    of step t+1 are issued before the MFMAs of step t and written to the other
-//    buffer after them; one workgroup barrier per step.  The four waves share every
-//    weight fragment, so L2 sees each weight byte once per 128 pixels.
+//    of step t+2 are issued at the start of step t and written to the free buffer at
+//    the start of step t+1 (a full step in flight); one workgroup barrier per step.
+//    The four waves share every weight fragment, so L2 sees each weight byte once per
+//    128 pixels.  The next input chunk / next unit's tile is likewise fetched into
+//    registers during the last step before it is needed.
 //  * The input halo tile sits in LDS one 64-channel chunk at a time ([position][64 B],
 //    stored as u8 - 128, 16-byte chunks XOR-swizzled like conv_mfma.cuh).
 //  * conv0 accumulates OCC 32-channel blocks at a time (D0[oc][px], weights = A
@@ -35,7 +40,7 @@
 namespace dfx {
 
 constexpr int ST_THREADS = 256;
-constexpr int ST_M = 128;  // pixel slots per unit
+constexpr int ST_M = 128;  // pixel slots per unit and PXB
 constexpr int ST_TQ = 4;   // tile granules (16 B) a thread stages with precomputed addresses
 
 struct StreamGeom {
@@ -50,15 +55,22 @@ struct StreamGeom {
   int n_g1, ks2;        // conv1: groups of G column blocks; k-steps (pairs of oc blocks)
   int s0_steps;         // conv0 steps per unit
   int mid_stride;       // bytes per slot of the intermediate (32 * ocb + 16)
-  int off_tile, off_pxoff, off_mid;  // LDS byte offsets (weight buffers at 0)
+  int off_tile, off_pxoff, off_mid, off_cst;  // LDS byte offsets (weight buffers at 0)
+  int fast;             // 1: the fast requant path is valid (host proof, see conv_mfma.cuh store_group)
+#ifdef DFX_STAMPS
+  unsigned long long *prof;  // diagnostic build only: [workgroup][wave][16] cycle sums
+#endif
 };
 
 // The LDS load feeding an MFMA operand must not be overtaken / re-targeted while the
 // MFMA is in flight (see conv_mfma.cuh): every step loads all its fragments into
 // distinct registers, fences, issues the MFMAs, fences.
 #define DFX_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifndef DFX_EXP
+#define DFX_EXP 0  // timing experiments (profiles/debug/exp_stream.sh): >0 builds produce wrong results
+#endif
 
-template <int OCC, int G, int DST, bool FUSED>
+template <int OCC, int G, int PXB, int DST, bool FUSED>
 __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, StreamGeom g) {
   constexpr int ESZ = (DST == DFX_F32 || DST == DFX_S32) ? 4 : 1;
   constexpr int WB = FUSED ? (OCC > G ? OCC : G) : OCC;  // fragments per half step a buffer holds
@@ -67,15 +79,16 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
   constexpr int NLD = (2 * WB * 64 + ST_THREADS - 1) / ST_THREADS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *tile = smem + g.off_tile;
-  int *pxoff = reinterpret_cast<int *>(smem + g.off_pxoff);
+  unsigned *pxoff = reinterpret_cast<unsigned *>(smem + g.off_pxoff);  // dst byte offset of each slot's pixel
   unsigned char *mid = smem + g.off_mid;
+  float *cst0 = reinterpret_cast<float *>(smem + g.off_cst);  // FUSED: comp0 | bias0 | scale0 in LDS
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
   const int OCP = 32 * g.ocb, OC1P = FUSED ? 32 * G * g.n_g1 : 0;
-  const int *comp0 = reinterpret_cast<const int *>(a.consts);
-  const float *bias0 = a.consts + OCP, *scale0 = a.consts + 2 * OCP;
+  const int *comp0 = reinterpret_cast<const int *>(FUSED ? cst0 : a.consts);
+  const float *bias0 = (FUSED ? cst0 : a.consts) + OCP, *scale0 = (FUSED ? cst0 : a.consts) + 2 * OCP;
   const int *comp1 = reinterpret_cast<const int *>(a.consts + 3 * OCP);
   const float *bias1 = a.consts + 3 * OCP + OC1P, *scale1 = a.consts + 3 * OCP + 2 * OC1P;
   const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -93,7 +106,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
     const int cnt_ = t_ < S0 ? GA : GB;                                                 \
     _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                   \
       const int q_ = tid + ST_THREADS * i;                                              \
-      if (q_ < cnt_) wreg[i] = wsrc[off_ + q_];                                         \
+      if (DFX_EXP != 1 && q_ < cnt_) wreg[i] = wsrc[off_ + q_];                         \
     }                                                                                   \
   } while (0)
 #define DFX_W_COMMIT(T, BUF)                                                            \
@@ -110,102 +123,190 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
   //      chunk q & 3; its image / row / column inside the halo tile never change ----
   const int lhw = g.lh * g.lw;
   const int tile_q = g.npos * 4;
-  int tq_rel[ST_TQ], tq_lds[ST_TQ], tq_pos[ST_TQ];  // src offset rel. to the tile origin, LDS offset, img<<20|ly<<10|lx
+  int tq_pos[ST_TQ];  // img << 20 | ly << 10 | lx of the granule's position
 #pragma unroll
   for (int i = 0; i < ST_TQ; ++i) {
     const int q = tid + ST_THREADS * i;
-    const int pos = min(q >> 2, g.npos - 1), j = q & 3;
+    const int pos = min(q >> 2, g.npos - 1);
     const int img = pos / lhw, r = pos - img * lhw;
     const int ly = r / g.lw, lx = r - ly * g.lw;
-    tq_rel[i] = ((img * a.ih + ly) * a.iw + lx) * a.ic + 16 * j;
-    tq_lds[i] = pos * 64 + 16 * (j ^ chunk_swizzle<4>(pos));
     tq_pos[i] = (img << 20) | (ly << 10) | lx;
   }
   const v4i x80 = v4i{(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
 
+  // ---- input tile prefetch registers (first ST_TQ granules per thread) ----
+  v4i tv[ST_TQ];
+#define DFX_T_ISSUE(ORG, IY0, IX0, NIMG, ICC)                                           \
+  do {                                                                                  \
+    const int cb0_ = 64 * (ICC);                                                        \
+    _Pragma("unroll") for (int i = 0; i < ST_TQ; ++i) {                                 \
+      const int q_ = tid + ST_THREADS * i;                                              \
+      const int img_ = tq_pos[i] >> 20, ly_ = (tq_pos[i] >> 10) & 1023, lx_ = tq_pos[i] & 1023; \
+      const int iy_ = (IY0) + ly_, ix_ = (IX0) + lx_;                                   \
+      const bool ok_ = q_ < tile_q && img_ < (NIMG) && iy_ >= 0 && iy_ < a.ih && ix_ >= 0 && \
+                       ix_ < a.iw && cb0_ + 16 * (q_ & 3) < a.ic;                       \
+      const int rel_ = ((img_ * a.ih + ly_) * a.iw + lx_) * a.ic + 16 * (q_ & 3);      \
+      tv[i] = v4i{0, 0, 0, 0};                                                          \
+      if (DFX_EXP != 6 && ok_) tv[i] = *reinterpret_cast<const v4i *>(a.src + ((ORG) + rel_ + cb0_)); \
+    }                                                                                   \
+  } while (0)
+#define DFX_T_COMMIT()                                                                  \
+  do {                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < ST_TQ; ++i) {                                 \
+      const int q_ = tid + ST_THREADS * i, pos_ = q_ >> 2;                              \
+      if (q_ < tile_q)                                                                  \
+        *reinterpret_cast<v4i *>(tile + pos_ * 64 + 16 * ((q_ & 3) ^ chunk_swizzle<4>(pos_))) = tv[i] ^ x80; \
+    }                                                                                   \
+  } while (0)
+
+  const int upg = g.uy * g.ux;
+  struct UnitGeo { int n0, y0, x0, nimg, iy0, ix0; long long org; };
+  auto unit_geo = [&](int unit) {
+    UnitGeo r;
+    const int grp = unit / upg, u = unit - grp * upg;
+    const int uyi = u / g.ux, uxi = u - uyi * g.ux;
+    r.n0 = grp * g.ni; r.y0 = uyi * g.thv; r.x0 = uxi * g.twv;
+    r.nimg = min(g.ni, a.bs - r.n0);
+    r.iy0 = r.y0 * a.sh - a.pt; r.ix0 = r.x0 * a.sw - a.pl;
+    // origin of the halo tile in src (may point before the image: only used with valid offsets)
+    r.org = (((long long)r.n0 * a.ih + r.iy0) * a.iw + r.ix0) * a.ic;
+    return r;
+  };
+  const bool fast = g.fast != 0;
+#ifdef DFX_STAMPS
+  unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  DFX_STAMP(t_entry);
+  using TT = std::true_type;
+  using FF = std::false_type;
+
+  // Weight pipeline invariant at the start of step t: LDS buffer `buf` holds step t,
+  // wreg holds (in flight) step t+1.
   int buf = 0;
   DFX_W_ISSUE(0);
   DFX_W_COMMIT(0, 0);
+  DFX_W_ISSUE(1 % S);
+  if (FUSED)
+    for (int q = tid; q < 3 * OCP; q += ST_THREADS) cst0[q] = a.consts[q];  // visible after the first staging barrier
+  bool tv_ready = false;  // tv holds the tile the next staging point needs
+#define DFX_STEP_WEIGHTS()                                                              \
+  {                                                                                     \
+    int t1_ = t + 1; if (t1_ >= S) t1_ -= S;                                            \
+    int t2_ = t1_ + 1; if (t2_ >= S) t2_ -= S;                                          \
+    DFX_W_COMMIT(t1_, buf ^ 1);                                                         \
+    DFX_W_ISSUE(t2_);                                                                   \
+  }
+#define DFX_STEP_END()  \
+  DFX_STAMP(b4);        \
+  if (DFX_EXP != 5) __syncthreads(); \
+  DFX_STAMP(b5);        \
+  DFX_ACC(3, b4 - b2);  \
+  DFX_ACC(4, b5 - b4);  \
+  DFX_ACC(2, b2 - b1);  \
+  buf ^= 1;             \
+  ++t
 
-  const int upg = g.uy * g.ux;
   for (int unit = blockIdx.x; unit < g.total_units; unit += gridDim.x) {
-    const int grp = unit / upg, u = unit - grp * upg;
-    const int uyi = u / g.ux, uxi = u - uyi * g.ux;
-    const int n0 = grp * g.ni, y0 = uyi * g.thv, x0 = uxi * g.twv;
-    const int nimg = min(g.ni, a.bs - n0), thc = min(g.thv, a.oh - y0), twc = min(g.twv, a.ow - x0);
-    const int npx = nimg * thc * twc;
-    // this lane's pixel slot (conv0 column / conv1 row)
-    const int slot = 32 * wave + l31;
-    int Pb;
-    {
+    DFX_STAMP(u0);
+    const UnitGeo ug = unit_geo(unit);
+    const int thc = min(g.thv, a.oh - ug.y0), twc = min(g.twv, a.ow - ug.x0);
+    const int npx = ug.nimg * thc * twc;
+    const bool has_next = unit + (int)gridDim.x < g.total_units;
+    const bool full = npx == ST_M * PXB;  // every slot holds a pixel: the stores need no predicate
+    // this lane's pixel slots (conv0 column / conv1 row), one per pixel block
+    int Pb[PXB];
+    unsigned char *my_mid[PXB];
+#pragma unroll
+    for (int pb = 0; pb < PXB; ++pb) {
+      const int slot = 32 * (wave * PXB + pb) + l31;
       const int pc = min(slot, npx - 1);
       const int img = pc / (thc * twc), r = pc - img * (thc * twc);
       const int ty = r / twc, tx = r - ty * twc;
-      Pb = img * lhw + ty * a.sh * g.lw + tx * a.sw;
-      if (h == 0) pxoff[slot] = slot < npx ? ((n0 + img) * a.oh + y0 + ty) * a.ow + x0 + tx : -1;
+      Pb[pb] = img * lhw + ty * a.sh * g.lw + tx * a.sw;
+      if (h == 0)
+        pxoff[slot] = slot < npx ? (unsigned)(((ug.n0 + img) * a.oh + ug.y0 + ty) * a.ow + ug.x0 + tx) * row_bytes
+                                 : 0xffffffffu;
+      my_mid[pb] = mid + slot * g.mid_stride + h * 16;
     }
-    const int iy0 = y0 * a.sh - a.pt, ix0 = x0 * a.sw - a.pl;
-    // origin of the halo tile in src (may point before the image: only used with valid offsets)
-    const long long org = (((long long)n0 * a.ih + iy0) * a.iw + ix0) * a.ic;
-    unsigned char *my_mid = mid + slot * g.mid_stride + h * 16;
 
     int t = 0;
     for (int occ = 0; occ < g.n_occ; ++occ) {
-      v16i acc[OCC];
+      v16i acc[PXB][OCC];
 #pragma unroll
-      for (int r = 0; r < OCC; ++r) acc[r] = zero16;
+      for (int pb = 0; pb < PXB; ++pb)
+#pragma unroll
+        for (int r = 0; r < OCC; ++r) acc[pb][r] = zero16;
+      // unfused: this chunk's requant constants travel while the MFMAs run
+      const int chb0 = 32 * OCC * occ + OCC * l31;  // unfused: lane owns channels chb0 .. chb0 + OCC-1
+      int cp0[OCC];
+      float bs0[OCC], sc0[OCC];
+      if (!FUSED) {
+#pragma unroll
+        for (int cc = 0; cc < OCC; ++cc) {
+          const int c = min(chb0 + cc, OCP - 1);
+          cp0[cc] = fast ? 0 : comp0[c];
+          bs0[cc] = bias0[c];
+          sc0[cc] = scale0[c];
+        }
+      }
       for (int icc = 0; icc < g.n_icc; ++icc) {
         // ---- stage input chunk icc of the halo tile (all waves are past the last
         //      step that read the previous contents: every step ends in a barrier).
         //      A single-chunk input stays in LDS for all output chunks of the unit. ----
         if (g.n_icc > 1 || occ == 0) {
+          DFX_STAMP(s0);
+          if (!tv_ready) DFX_T_ISSUE(ug.org, ug.iy0, ug.ix0, ug.nimg, icc);
+          DFX_T_COMMIT();
+          tv_ready = false;
           const int cb0 = 64 * icc;
-          v4i tv[ST_TQ];
-#pragma unroll
-          for (int i = 0; i < ST_TQ; ++i) {
-            const int q = tid + ST_THREADS * i;
-            const int img = tq_pos[i] >> 20, ly = (tq_pos[i] >> 10) & 1023, lx = tq_pos[i] & 1023;
-            const int iy = iy0 + ly, ix = ix0 + lx;
-            const bool ok = q < tile_q && img < nimg && iy >= 0 && iy < a.ih && ix >= 0 && ix < a.iw &&
-                            cb0 + 16 * (q & 3) < a.ic;
-            tv[i] = v4i{0, 0, 0, 0};
-            if (ok) tv[i] = *reinterpret_cast<const v4i *>(a.src + (org + tq_rel[i] + cb0));
-          }
-#pragma unroll
-          for (int i = 0; i < ST_TQ; ++i)
-            if (tid + ST_THREADS * i < tile_q) *reinterpret_cast<v4i *>(tile + tq_lds[i]) = tv[i] ^ x80;
           for (int q = tid + ST_THREADS * ST_TQ; q < tile_q; q += ST_THREADS) {  // oversized tiles
             const int pos = q >> 2, j = q & 3;
             const int img = pos / lhw, r = pos - img * lhw;
             const int ly = r / g.lw, lx = r - ly * g.lw;
-            const int iy = iy0 + ly, ix = ix0 + lx;
-            const bool ok = img < nimg && iy >= 0 && iy < a.ih && ix >= 0 && ix < a.iw && cb0 + 16 * j < a.ic;
+            const int iy = ug.iy0 + ly, ix = ug.ix0 + lx;
+            const bool ok = img < ug.nimg && iy >= 0 && iy < a.ih && ix >= 0 && ix < a.iw && cb0 + 16 * j < a.ic;
             v4i v = v4i{0, 0, 0, 0};
             if (ok)
               v = *reinterpret_cast<const v4i *>(
-                  a.src + (org + (long long)((img * a.ih + ly) * a.iw + lx) * a.ic + 16 * j + cb0));
+                  a.src + (ug.org + (long long)((img * a.ih + ly) * a.iw + lx) * a.ic + 16 * j + cb0));
             *reinterpret_cast<v4i *>(tile + pos * 64 + 16 * (j ^ chunk_swizzle<4>(pos))) = v ^ x80;
           }
           __syncthreads();
+          DFX_STAMP(s1);
+          DFX_ACC(0, s1 - s0);
         }
         const int kbn = min(2, g.icb - 2 * icc);  // 32-channel blocks in this chunk
         const int ntap = a.kh * a.kw;
         const int ns = ntap * kbn, ns2 = (ns + 1) >> 1;
         int tkh = 0, tkw = 0;  // tap of k-block s (kept incrementally)
         for (int s2 = 0; s2 < ns2; ++s2) {
-          int tn = t + 1;
-          if (tn == S) tn = 0;
-          DFX_W_ISSUE(tn);
+          DFX_STAMP(b0);
+          DFX_STAMP(b1);
+          if (s2 == ns2 - 1) {  // last step before the next staging point: fetch its tile now
+            if (g.n_icc > 1 && (icc + 1 < g.n_icc || occ + 1 < g.n_occ)) {
+              DFX_T_ISSUE(ug.org, ug.iy0, ug.ix0, ug.nimg, icc + 1 < g.n_icc ? icc + 1 : 0);
+              tv_ready = true;
+            } else if (!FUSED && occ + 1 == g.n_occ && has_next) {
+              const UnitGeo nx = unit_geo(unit + gridDim.x);
+              DFX_T_ISSUE(nx.org, nx.iy0, nx.ix0, nx.nimg, 0);
+              tv_ready = true;
+            }
+          }
           const unsigned char *wb = smem + buf * WBUF;
-          v4i fb[2], fw[2][OCC];
+          v4i fb[2][PXB], fw[2][OCC];
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int s = 2 * s2 + j;
             const int icbl = kbn == 2 ? j : 0;
-            const int P = Pb + tkh * g.lw + tkw;
-            fb[j] = *reinterpret_cast<const v4i *>(tile + P * 64 + 16 * ((2 * icbl + h) ^ chunk_swizzle<4>(P)));
+#pragma unroll
+            for (int pb = 0; pb < PXB; ++pb) {
+              const int P = Pb[pb] + tkh * g.lw + tkw;
+              if (DFX_EXP == 4) { fb[j][pb] = v4i{P, P, P, P}; } else
+              fb[j][pb] = *reinterpret_cast<const v4i *>(tile + P * 64 + 16 * ((2 * icbl + h) ^ chunk_swizzle<4>(P)));
+            }
 #pragma unroll
             for (int r = 0; r < OCC; ++r)
+              if (DFX_EXP == 4) { fw[j][r] = v4i{lane16, buf, r, j}; } else
               fw[j][r] = *reinterpret_cast<const v4i *>(wb + (j * OCC + r) * 1024 + lane16);
             // advance the tap after the chunk's last k-block of it; a padding k-block
             // (s >= ns, zero weights) re-reads the last tap
@@ -214,132 +315,207 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
             }
           }
           DFX_FENCE();
+          DFX_STAMP(b2);  // (diagnostic builds: waits for the fragments)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < 2; ++j) {
 #pragma unroll
             for (int r = 0; r < OCC; ++r)
-              acc[r] = FUSED ? mfma_i8(fw[j][r], fb[j], acc[r])   // D0[oc][px]
-                             : mfma_i8(fb[j], fw[j][r], acc[r]);  // D0[px][oc]
-          DFX_FENCE();
-          DFX_W_COMMIT(tn, buf ^ 1);
-          __syncthreads();
-          buf ^= 1;
-          ++t;
+#pragma unroll
+              for (int pb = 0; pb < PXB; ++pb)
+                if (DFX_EXP != 3)
+                  acc[pb][r] = FUSED ? mfma_i8(fw[j][r], fb[j][pb], acc[pb][r])   // D0[oc][px]
+                                     : mfma_i8(fb[j][pb], fw[j][r], acc[pb][r]);  // D0[px][oc]
+            DFX_FENCE();
+            if (j == 0) {  // the weight pipeline's VALU / LDS-write work runs under the first MFMAs
+              DFX_STEP_WEIGHTS();
+              DFX_FENCE();
+            }
+          }
+          DFX_STEP_END();
         }
       }
+      DFX_STAMP(e0);
       if constexpr (FUSED) {
         // ---- requant 0 -> u8 -> this wave's rows of mid, in the 1x1 stage's k order:
         //      byte 16h + 4q + i of block r  =  channel 32r + 8q + 4h + i ----
+#pragma unroll
+        for (int pb = 0; pb < PXB; ++pb)
 #pragma unroll
         for (int r = 0; r < OCC; ++r) {
           v4i pkv;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int ch = (occ * OCC + r) * 32 + 8 * q + 4 * h;
-            const v4i cp = *reinterpret_cast<const v4i *>(comp0 + ch);
             const v4f bs = *reinterpret_cast<const v4f *>(bias0 + ch);
             const v4f sc = *reinterpret_cast<const v4f *>(scale0 + ch);
             unsigned pk = 0;
+            if (fast) {  // bias slot = comp + bias (exact); ReLU + RNE + saturation in v_cvt_pk_u8_f32
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float f = requant(acc[r][4 * q + i] + cp[i], bs[i], sc[i], true);
-              pk |= sat_u8_bits(cvt_x86_rt(f, a.rm0)) << (8 * i);
+              for (int i = 0; i < 4; i += 2) {
+                v2f x = {__int2float_rn(acc[pb][r][4 * q + i]), __int2float_rn(acc[pb][r][4 * q + i + 1])};
+                x = (x + v2f{bs[i], bs[i + 1]}) * v2f{sc[i], sc[i + 1]};
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(x[0], i, pk);
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(x[1], i + 1, pk);
+              }
+            } else {
+              const v4i cp = *reinterpret_cast<const v4i *>(comp0 + ch);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const float f = requant(acc[pb][r][4 * q + i] + cp[i], bs[i], sc[i], true);
+                pk |= sat_u8_bits(cvt_x86_rt(f, a.rm0)) << (8 * i);
+              }
             }
             pkv[q] = (int)(pk ^ 0x80808080u);
           }
-          *reinterpret_cast<v4i *>(my_mid + (occ * OCC + r) * 32) = pkv;
+          *reinterpret_cast<v4i *>(my_mid[pb] + (occ * OCC + r) * 32) = pkv;
         }
       } else {
         // ---- unfused: typed store; lane owns channels 32*OCC*occ + OCC*l31 + {0..OCC-1} ----
-        const int chb = 32 * OCC * occ + OCC * l31;
-        if (chb < a.oc) {
-          int cp[OCC];
-          float bs[OCC], sc[OCC], zf[OCC];
+        if (chb0 < a.oc) {
+          float zf[OCC];
 #pragma unroll
-          for (int cc = 0; cc < OCC; ++cc) {
-            cp[cc] = comp0[chb + cc];
-            bs[cc] = bias0[chb + cc];
-            sc[cc] = scale0[chb + cc];
-            zf[cc] = 0.0f;
-          }
+          for (int cc = 0; cc < OCC; ++cc) zf[cc] = 0.0f;
           const bool relu = a.relu0 || DST == DFX_U8;
+          unsigned char *dst_b = reinterpret_cast<unsigned char *>(a.dst);
+          const unsigned chbE = (unsigned)chb0 * ESZ;
+          auto emit0 = [&](auto fast_tag, auto check_tag) {
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int off = pxoff[32 * wave + 8 * (e >> 2) + (e & 3) + 4 * h];
-            if (off >= 0) {
-              int v[OCC];
+            for (int pb = 0; pb < PXB; ++pb)
 #pragma unroll
-              for (int cc = 0; cc < OCC; ++cc) v[cc] = acc[cc][e] + cp[cc];
-              store_group<DST, OCC, false>(reinterpret_cast<unsigned char *>(a.dst) + (size_t)off * row_bytes +
-                                               (unsigned)chb * ESZ,
-                                           v, zf, bs, sc, relu, a.rm0);
-            }
-          }
+              for (int eq = 0; eq < 4; ++eq) {
+                const v4i o4 = *reinterpret_cast<const v4i *>(pxoff + 32 * (wave * PXB + pb) + 8 * eq + 4 * h);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  const unsigned off = (unsigned)o4[i];
+                  if (!decltype(check_tag)::value || off != 0xffffffffu) {
+                    int v[OCC];
+#pragma unroll
+                    for (int cc = 0; cc < OCC; ++cc) v[cc] = acc[pb][cc][4 * eq + i] + cp0[cc];
+                    store_group<DST, OCC, decltype(fast_tag)::value>(dst_b + (size_t)(off + chbE), v, zf, bs0, sc0,
+                                                                     relu, a.rm0);
+                  }
+                }
+              }
+          };
+          if (DFX_EXP == 2) { if (acc[0][0][0] == 0x12345678) emit0(TT{}, TT{}); }
+          else if (fast) { if (full) emit0(TT{}, FF{}); else emit0(TT{}, TT{}); }
+          else      { if (full) emit0(FF{}, FF{}); else emit0(FF{}, TT{}); }
         }
       }
+      DFX_STAMP(e1);
+      DFX_ACC(5, e1 - e0);
     }
 
     if constexpr (FUSED) {
       // ---- conv1 over mid, G column blocks at a time ----
       const bool relu = a.relu1 || DST == DFX_U8;
       for (int g1 = 0; g1 < g.n_g1; ++g1) {
-        v16i acc1[G];
+        v16i acc1[PXB][G];
 #pragma unroll
-        for (int cc = 0; cc < G; ++cc) acc1[cc] = zero16;
+        for (int pb = 0; pb < PXB; ++pb)
+#pragma unroll
+          for (int cc = 0; cc < G; ++cc) acc1[pb][cc] = zero16;
+        // this group's requant constants travel while the MFMAs run
+        const int chb = 32 * G * g1 + G * l31;
+        int cp[G];
+        float bs[G], sc[G], zf[G];
+#pragma unroll
+        for (int cc = 0; cc < G; ++cc) {
+          cp[cc] = fast ? 0 : comp1[chb + cc];
+          bs[cc] = bias1[chb + cc];
+          sc[cc] = scale1[chb + cc];
+          zf[cc] = 0.0f;
+        }
         for (int s2 = 0; s2 < g.ks2; ++s2) {
-          int tn = t + 1;
-          if (tn == S) tn = 0;
-          DFX_W_ISSUE(tn);
+          DFX_STAMP(b0);
+          DFX_STAMP(b1);
+          if (g1 + 1 == g.n_g1 && s2 + 1 == g.ks2 && has_next) {  // next unit's first tile
+            const UnitGeo nx = unit_geo(unit + gridDim.x);
+            DFX_T_ISSUE(nx.org, nx.iy0, nx.ix0, nx.nimg, 0);
+            tv_ready = true;
+          }
           const unsigned char *wb = smem + buf * WBUF;
-          v4i fa[2], fw[2][G];
+          v4i fa[2][PXB], fw[2][G];
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int blk = min(2 * s2 + j, g.ocb - 1);  // a padding k-block has zero weights
-            fa[j] = *reinterpret_cast<const v4i *>(my_mid + blk * 32);
+#pragma unroll
+            for (int pb = 0; pb < PXB; ++pb)
+              if (DFX_EXP == 4) { fa[j][pb] = v4i{blk, lane16, pb, j}; } else
+              fa[j][pb] = *reinterpret_cast<const v4i *>(my_mid[pb] + blk * 32);
 #pragma unroll
             for (int cc = 0; cc < G; ++cc)
+              if (DFX_EXP == 4) { fw[j][cc] = v4i{lane16, buf, cc, j}; } else
               fw[j][cc] = *reinterpret_cast<const v4i *>(wb + (j * G + cc) * 1024 + lane16);
           }
           DFX_FENCE();
+          DFX_STAMP(b2);
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < 2; ++j) {
 #pragma unroll
-            for (int cc = 0; cc < G; ++cc) acc1[cc] = mfma_i8(fa[j], fw[j][cc], acc1[cc]);
-          DFX_FENCE();
-          DFX_W_COMMIT(tn, buf ^ 1);
-          __syncthreads();
-          buf ^= 1;
-          ++t;
-        }
-        const int chb = 32 * G * g1 + G * l31;
-        if (chb < a.oc1) {
-          int cp[G];
-          float bs[G], sc[G], zf[G];
+            for (int cc = 0; cc < G; ++cc)
 #pragma unroll
-          for (int cc = 0; cc < G; ++cc) {
-            cp[cc] = comp1[chb + cc];
-            bs[cc] = bias1[chb + cc];
-            sc[cc] = scale1[chb + cc];
-            zf[cc] = 0.0f;
-          }
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int off = pxoff[32 * wave + 8 * (e >> 2) + (e & 3) + 4 * h];
-            if (off >= 0) {
-              int v[G];
-#pragma unroll
-              for (int cc = 0; cc < G; ++cc) v[cc] = acc1[cc][e] + cp[cc];
-              store_group<DST, G, false>(reinterpret_cast<unsigned char *>(a.dst) + (size_t)off * row_bytes +
-                                             (unsigned)chb * ESZ,
-                                         v, zf, bs, sc, relu, a.rm1);
+              for (int pb = 0; pb < PXB; ++pb)
+                if (DFX_EXP != 3) acc1[pb][cc] = mfma_i8(fa[j][pb], fw[j][cc], acc1[pb][cc]);
+            DFX_FENCE();
+            if (j == 0) {
+              DFX_STEP_WEIGHTS();
+              DFX_FENCE();
             }
           }
+          DFX_STEP_END();
         }
+        DFX_STAMP(e2);
+        if (chb < a.oc1) {
+          unsigned char *dst_b = reinterpret_cast<unsigned char *>(a.dst);
+          const unsigned chbE = (unsigned)chb * ESZ;
+          auto emit1 = [&](auto fast_tag, auto check_tag) {
+#pragma unroll
+            for (int pb = 0; pb < PXB; ++pb)
+#pragma unroll
+              for (int eq = 0; eq < 4; ++eq) {
+                const v4i o4 = *reinterpret_cast<const v4i *>(pxoff + 32 * (wave * PXB + pb) + 8 * eq + 4 * h);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  const unsigned off = (unsigned)o4[i];
+                  if (!decltype(check_tag)::value || off != 0xffffffffu) {
+                    int v[G];
+#pragma unroll
+                    for (int cc = 0; cc < G; ++cc) v[cc] = acc1[pb][cc][4 * eq + i] + cp[cc];
+                    store_group<DST, G, decltype(fast_tag)::value>(dst_b + (size_t)(off + chbE), v, zf, bs, sc, relu,
+                                                                   a.rm1);
+                  }
+                }
+              }
+          };
+          if (DFX_EXP == 2) { if (acc1[0][0][0] == 0x12345678) emit1(TT{}, TT{}); }
+          else if (fast) { if (full) emit1(TT{}, FF{}); else emit1(TT{}, TT{}); }
+          else      { if (full) emit1(FF{}, FF{}); else emit1(FF{}, TT{}); }
+        }
+        DFX_STAMP(e3);
+        DFX_ACC(6, e3 - e2);
       }
     }
+    DFX_STAMP(u1);
+    DFX_ACC(7, u1 - u0);
+    DFX_ACC(8, 1);
   }
+#ifdef DFX_STAMPS
+  {
+    DFX_STAMP(t_end);
+    if (lane == 0) {
+      unsigned long long *o = g.prof + ((size_t)blockIdx.x * 4 + wave) * 16;
+      for (int k = 0; k < 9; ++k) o[k] = prof_acc[k];
+      o[9] = t_end - t_entry;
+    }
+  }
+#endif
 #undef DFX_W_ISSUE
 #undef DFX_W_COMMIT
+#undef DFX_T_ISSUE
+#undef DFX_T_COMMIT
+#undef DFX_STEP_WEIGHTS
+#undef DFX_STEP_END
 }
 
 }  // namespace dfx

@@ -42,7 +42,7 @@ DFX_DECL(u8);
 #undef DFX_DECL
 
 #define DFX_DECL(n) \
-  int launch_conv_stream_##n(const ConvArgs &, const StreamGeom &, int, int, int, int, int, hipStream_t, int)
+  int launch_conv_stream_##n(const ConvArgs &, const StreamGeom &, int, int, int, int, int, int, hipStream_t, int)
 DFX_DECL(f32);
 DFX_DECL(s32);
 DFX_DECL(s8);
@@ -80,7 +80,7 @@ struct dfx_conv {
   ConvArgs args;
   MfmaGeom geom;
   StreamGeom sgeom;  // DFX_VARIANT_MFMA_STREAM
-  int occ;           // stream variant: conv0 output blocks per chunk
+  int occ, pxb;      // stream variant: conv0 output blocks per chunk, pixel blocks per wave
   int icb, ocb, G, grid, block, lds;
   void *d_wei, *d_wei1, *d_consts;
   int *d_queue;  // MFMA variant: {next unit, finished workgroups}
@@ -308,7 +308,8 @@ static int pick_blocking(int nblocks) {
   return 1;
 }
 
-static bool pick_stream_geometry(const dfx_conv_desc &d, int OCC, int G, StreamGeom &g, int &lds) {
+static bool pick_stream_geometry(const dfx_conv_desc &d, int OCC, int G, int PXB, StreamGeom &g, int &lds) {
+  const int M = ST_M * PXB;  // pixel slots per unit
   const bool fused = d.oc1x1 > 0;
   const int icb = (d.ic + 31) / 32, ocb_real = (d.oc + 31) / 32;
   g.icb = icb;
@@ -322,10 +323,13 @@ static bool pick_stream_geometry(const dfx_conv_desc &d, int OCC, int G, StreamG
   for (int c = 0; c < g.n_icc; ++c) s0 += (d.kh * d.kw * std::min(2, icb - 2 * c) + 1) / 2;
   g.s0_steps = s0 * g.n_occ;
   const int WB = fused ? std::max(OCC, G) : OCC;
-  const size_t fixed = (size_t)2 * 2 * WB * 1024 + 4 * ST_M + (fused ? (size_t)ST_M * g.mid_stride : 0);
+  const size_t cst_bytes = fused ? round16((size_t)3 * 32 * g.ocb * 4) : 0;
+  const size_t fixed = (size_t)2 * 2 * WB * 1024 + 4 * M + (fused ? (size_t)M * g.mid_stride : 0) + cst_bytes;
   const size_t lds_max = 163840;
   // index ranges the kernel keeps in 32 bits / packed fields
-  if ((long long)d.bs * d.oh * d.ow >= (1LL << 31) || (long long)d.ih * d.iw * d.ic * ST_M >= (1LL << 31)) return false;
+  // (dst byte offsets are 32-bit in the kernel's pixel table)
+  if ((long long)d.bs * d.oh * d.ow * (d.oc1x1 ? d.oc1x1 : d.oc) * (long long)dt_size(d.dst_dt) >= (1LL << 32) - 16 ||
+      (long long)d.bs * d.oh * d.ow >= (1LL << 31) || (long long)d.ih * d.iw * d.ic * M >= (1LL << 31)) return false;
   double best = -1.0;
   auto consider = [&](int ni, int thv, int twv) {
     const int lh = (thv - 1) * d.sh + d.kh, lw = (twv - 1) * d.sw + d.kw;
@@ -334,7 +338,7 @@ static bool pick_stream_geometry(const dfx_conv_desc &d, int OCC, int G, StreamG
     if (fixed + (size_t)npos * 64 > lds_max) return;
     const double groups = (double)((d.bs + ni - 1) / ni);
     const double units = groups * ((d.oh + thv - 1) / thv) * ((d.ow + twv - 1) / twv);
-    const double util = (double)d.bs * d.oh * d.ow / (units * ST_M);        // filled pixel slots
+    const double util = (double)d.bs * d.oh * d.ow / (units * M);           // filled pixel slots
     const double halo = (double)thv * d.sh * twv * d.sw / ((double)lh * lw);  // input re-read
     const double score = util * (0.8 + 0.2 * std::min(1.0, halo));
     if (score > best) {
@@ -342,10 +346,10 @@ static bool pick_stream_geometry(const dfx_conv_desc &d, int OCC, int G, StreamG
       g.ni = ni; g.thv = thv; g.twv = twv; g.lh = lh; g.lw = lw; g.npos = (int)npos;
     }
   };
-  if (d.oh * d.ow <= ST_M) {
-    for (int ni = std::min(d.bs, ST_M / (d.oh * d.ow)); ni >= 1; --ni) consider(ni, d.oh, d.ow);
+  if (d.oh * d.ow <= M) {
+    for (int ni = std::min(d.bs, M / (d.oh * d.ow)); ni >= 1; --ni) consider(ni, d.oh, d.ow);
   } else {
-    for (int twv = 1; twv <= std::min(d.ow, ST_M); ++twv) consider(1, std::min(d.oh, ST_M / twv), twv);
+    for (int twv = 1; twv <= std::min(d.ow, M); ++twv) consider(1, std::min(d.oh, M / twv), twv);
   }
   if (best < 0) return false;
   g.uy = (d.oh + g.thv - 1) / g.thv;
@@ -353,18 +357,19 @@ static bool pick_stream_geometry(const dfx_conv_desc &d, int OCC, int G, StreamG
   g.total_units = (d.bs + g.ni - 1) / g.ni * g.uy * g.ux;
   g.off_tile = 2 * 2 * WB * 1024;
   g.off_pxoff = (int)round16((size_t)g.off_tile + (size_t)g.npos * 64);
-  g.off_mid = g.off_pxoff + 4 * ST_M;
-  lds = g.off_mid + (fused ? ST_M * g.mid_stride : 0);
+  g.off_mid = g.off_pxoff + 4 * M;
+  g.off_cst = g.off_mid + (fused ? M * g.mid_stride : 0);
+  lds = g.off_cst + (int)cst_bytes;
   return true;
 }
 
 static int stream_dispatch(dfx_conv *h, hipStream_t s, int mode) {
   const int fused = h->d.oc1x1 > 0;
   switch (h->d.dst_dt) {
-    case DFX_F32: return launch_conv_stream_f32(h->args, h->sgeom, h->occ, h->G, fused, h->grid, h->lds, s, mode);
-    case DFX_S32: return launch_conv_stream_s32(h->args, h->sgeom, h->occ, h->G, fused, h->grid, h->lds, s, mode);
-    case DFX_S8: return launch_conv_stream_s8(h->args, h->sgeom, h->occ, h->G, fused, h->grid, h->lds, s, mode);
-    case DFX_U8: return launch_conv_stream_u8(h->args, h->sgeom, h->occ, h->G, fused, h->grid, h->lds, s, mode);
+    case DFX_F32: return launch_conv_stream_f32(h->args, h->sgeom, h->occ, h->G, h->pxb, fused, h->grid, h->lds, s, mode);
+    case DFX_S32: return launch_conv_stream_s32(h->args, h->sgeom, h->occ, h->G, h->pxb, fused, h->grid, h->lds, s, mode);
+    case DFX_S8: return launch_conv_stream_s8(h->args, h->sgeom, h->occ, h->G, h->pxb, fused, h->grid, h->lds, s, mode);
+    case DFX_U8: return launch_conv_stream_u8(h->args, h->sgeom, h->occ, h->G, h->pxb, fused, h->grid, h->lds, s, mode);
   }
   return -1;
 }
@@ -423,7 +428,29 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
   if (want_stream) {
     h->occ = pick_blocking((d.oc + 31) / 32);
     h->G = d.oc1x1 ? pick_blocking((d.oc1x1 + 31) / 32) : h->occ;
-    stream_ok = pick_stream_geometry(d, h->occ, h->G, h->sgeom, h->lds);
+    if (const char *e = getenv("DFX_STREAM_BLOCKING")) {  // tuning aid: "occ,g" from {1,2,4}
+      int o = 0, gg = 0;
+      if (sscanf(e, "%d,%d", &o, &gg) == 2 && (o == 1 || o == 2 || o == 4) && (gg == 1 || gg == 2 || gg == 4)) {
+        h->occ = o;
+        h->G = d.oc1x1 ? gg : o;
+      }
+    }
+    // Two pixel blocks per wave halve the LDS fragment traffic per MFMA but double the unit:
+    // taken when the units still fill the machine twice over, and when it fits LDS.
+    int ncu = 256;
+    {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    }
+    h->pxb = 2;
+    if (const char *e = getenv("DFX_STREAM_PXB")) h->pxb = atoi(e) == 1 ? 1 : 2;  // tuning aid
+    stream_ok = h->pxb == 2 && pick_stream_geometry(d, h->occ, h->G, 2, h->sgeom, h->lds) &&
+                (h->sgeom.total_units >= 4 * ncu || getenv("DFX_STREAM_PXB"));
+    if (!stream_ok) {
+      h->pxb = 1;
+      stream_ok = pick_stream_geometry(d, h->occ, h->G, 1, h->sgeom, h->lds);
+    }
     if (!stream_ok && d.force_variant == DFX_VARIANT_MFMA_STREAM) {
       delete h;
       return fail(DFX_ERR_UNSUPPORTED, "conv_create: shape does not fit the streamed MFMA variant");
@@ -445,10 +472,18 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     int per_cu = mfma_dispatch(h, nullptr, 2);
     if (per_cu < 1) per_cu = 1;
     h->grid = std::min(h->sgeom.total_units, prop.multiProcessorCount * per_cu);
+#ifdef DFX_STAMPS
+    if (hipMalloc((void **)&h->d_prof, (size_t)h->grid * 64 * 8) != hipSuccess ||
+        hipMemset(h->d_prof, 0, (size_t)h->grid * 64 * 8) != hipSuccess) {
+      delete h;
+      return fail(DFX_ERR_HIP, "conv_create: cannot allocate the stamp buffer");
+    }
+    h->sgeom.prof = h->d_prof;
+#endif
     a.rows_per_unit = h->sgeom.thv;
     a.units_per_image = h->sgeom.uy * h->sgeom.ux;
-    snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_stream_kernel<%d,%d,%d,%s>", h->occ, h->G, d.dst_dt,
-             d.oc1x1 ? "fused" : "unfused");
+    snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_stream_kernel<%d,%d,%d,%d,%s>", h->occ, h->G, h->pxb,
+             d.dst_dt, d.oc1x1 ? "fused" : "unfused");
   } else if (want_mfma && pick_geometry(d, h->geom, h->lds)) {
     const bool fused = d.oc1x1 > 0;
     h->variant = fused ? DFX_VARIANT_MFMA_FUSED : DFX_VARIANT_MFMA_CONV;
@@ -516,6 +551,18 @@ static float bias_to_f32(const void *b, int dt, int c) {
   return 0.0f;
 }
 
+// One channel's precondition of the fast requant path (conv_mfma.cuh store_group<FAST>):
+// amax bounds |true accumulator|; comp + bias must fold into ONE exact f32 add (bias
+// integer-valued, |comp + bias| < 2^24, |acc + bias| < 2^24) and nothing may reach +-2^31.
+static bool fast_ok_channel(double amax, double comp, float bias, float scale) {
+  if (!std::isfinite(bias) || !std::isfinite(scale)) return false;
+  const double b = bias;
+  if (b != std::floor(b)) return false;
+  const double lim = 16777216.0;  // 2^24
+  if (std::fabs(comp + b) >= lim || amax + std::fabs(b) >= lim || std::fabs(comp) + amax >= lim) return false;
+  return (amax + std::fabs(b)) * std::fabs((double)scale) * 1.0001 + 2.0 < 2147480000.0;
+}
+
 // Packs weights for conv_stream.cuh: ONE device buffer
 //   [conv0 steps | conv1 steps | consts], a step = 2 k-blocks x (OCC | G) fragments of 1 KB,
 // in the exact order the kernel walks them (oc chunk, ic chunk, step; 1x1 group, step).
@@ -566,21 +613,44 @@ static int set_weights_stream(dfx_conv_t *h, const int8_t *wei, const void *bia0
   // channels are all-zero (their intermediate is 0 and meets zero 1x1 weights)
   std::vector<int32_t> cst((size_t)3 * (OCP + OC1P), 0);
   auto put_f = [&](size_t idx, float v) { memcpy(&cst[idx], &v, 4); };
+  bool fast = d.conv0_round_mode == DFX_ROUND_NEAREST && (!fused || d.conv1_round_mode == DFX_ROUND_NEAREST);
+  std::vector<float> fb0(OC), fb1(OC1 ? OC1 : 1);  // bias as f32
   for (int c = 0; c < OC; ++c) {
-    int32_t sum = 0;
+    int32_t sum = 0, pos = 0, neg = 0;
     for (int ic = 0; ic < IC; ++ic)
-      for (int tap = 0; tap < ntap; ++tap) sum += wei[dfx_blocked_offset(c, ic, tap / d.kw, tap % d.kw, IC, d.kh, d.kw)];
+      for (int tap = 0; tap < ntap; ++tap) {
+        const int w = wei[dfx_blocked_offset(c, ic, tap / d.kw, tap % d.kw, IC, d.kh, d.kw)];
+        sum += w;
+        (w > 0 ? pos : neg) += w;
+      }
     cst[c] = 128 * sum;
-    put_f((size_t)OCP + c, d.bia0_dt == DFX_UNDEF ? 0.0f : bias_to_f32(bia0, d.bia0_dt, c));
-    put_f((size_t)2 * OCP + c, scales0[d.conv0_nscales > 1 ? c : 0]);
+    fb0[c] = d.bia0_dt == DFX_UNDEF ? 0.0f : bias_to_f32(bia0, d.bia0_dt, c);
+    const float sc = scales0[d.conv0_nscales > 1 ? c : 0];
+    put_f((size_t)OCP + c, fb0[c]);
+    put_f((size_t)2 * OCP + c, sc);
+    fast = fast && fast_ok_channel(255.0 * std::max(pos, -neg), 128.0 * sum, fb0[c], sc);
   }
   for (int c = 0; c < OC1; ++c) {
-    int32_t sum = 0;
-    for (int oc = 0; oc < OC; ++oc) sum += wei1[dfx_blocked_offset(c, oc, 0, 0, OC, 1, 1)];
+    int32_t sum = 0, pos = 0, neg = 0;
+    for (int oc = 0; oc < OC; ++oc) {
+      const int w = wei1[dfx_blocked_offset(c, oc, 0, 0, OC, 1, 1)];
+      sum += w;
+      (w > 0 ? pos : neg) += w;
+    }
     cst[(size_t)3 * OCP + c] = 128 * sum;
-    put_f((size_t)3 * OCP + OC1P + c, d.bia1_dt == DFX_UNDEF ? 0.0f : bias_to_f32(bia1, d.bia1_dt, c));
-    put_f((size_t)3 * OCP + 2 * OC1P + c, scales1[d.conv1_nscales > 1 ? c : 0]);
+    fb1[c] = d.bia1_dt == DFX_UNDEF ? 0.0f : bias_to_f32(bia1, d.bia1_dt, c);
+    const float sc = scales1[d.conv1_nscales > 1 ? c : 0];
+    put_f((size_t)3 * OCP + OC1P + c, fb1[c]);
+    put_f((size_t)3 * OCP + 2 * OC1P + c, sc);
+    fast = fast && fast_ok_channel(255.0 * std::max(pos, -neg), 128.0 * sum, fb1[c], sc);
   }
+  if (const char *e = getenv("DFX_NO_FAST")) fast = fast && atoi(e) == 0;  // testing aid: force the exact path
+  if (fast) {  // the fast path reads comp + bias (an exact f32) from the bias slot
+    for (int c = 0; c < OC; ++c) put_f((size_t)OCP + c, (float)((double)cst[c] + (double)fb0[c]));
+    for (int c = 0; c < OC1; ++c)
+      put_f((size_t)3 * OCP + OC1P + c, (float)((double)cst[(size_t)3 * OCP + c] + (double)fb1[c]));
+  }
+  h->sgeom.fast = fast ? 1 : 0;
   if (!h->d_wei) HIP_TRY(hipMalloc(&h->d_wei, pk.size() + cst.size() * 4));
   char *base = (char *)h->d_wei;
   HIP_TRY(hipMemcpy(base, pk.data(), pk.size(), hipMemcpyHostToDevice));
@@ -785,7 +855,7 @@ int dfx_conv_query(const dfx_conv_t *h, dfx_conv_info *info) {
 // diagnostic build only: copies the [grid][8 waves][8] stamp sums of the last launch
 int dfx_debug_read_stamps(dfx_conv_t *h, unsigned long long *out, int max_entries) {
   if (!h || !h->d_prof) return fail(DFX_ERR_STATE, "no stamps");
-  int n = h->grid * 256;
+  int n = h->grid * (h->variant == DFX_VARIANT_MFMA_STREAM ? 64 : 256);
   if (n > max_entries) n = max_entries;
   HIP_TRY(hipMemcpy(out, h->d_prof, (size_t)n * 8, hipMemcpyDeviceToHost));
   return n;

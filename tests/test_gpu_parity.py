@@ -109,6 +109,16 @@ def test_stream_variant(hip, oracle, case):
     hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), info.kernel_name.decode())
 
 
+def test_stream_variant_exact_requant_path(hip, oracle, monkeypatch):
+    """DFX_NO_FAST=1 (read at set_weights) forces the exact requant code path on inputs the
+    fast-path proof would otherwise accept."""
+    monkeypatch.setenv("DFX_NO_FAST", "1")
+    for case in STREAM_SHAPES[:12] + C.dtype_matrix(C.SMALL) + [C.unfused(c) for c in C.dtype_matrix(C.SMALL)]:
+        data = C.generate(case)
+        got, info = hip.hip_conv(case, data, force_variant=hip.dfa.VARIANT_MFMA_STREAM)
+        hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), case.ident())
+
+
 def test_auto_variant_prefers_mfma(hip):
     """shapes outside the resident-weight kernel go to the streamed MFMA kernel, not the scalar one."""
     for case in STREAM_SHAPES[:4]:
