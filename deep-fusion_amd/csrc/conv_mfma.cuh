@@ -201,6 +201,30 @@ __device__ __forceinline__ void store_group(unsigned char *p, const int (&acc)[G
   }
 }
 
+// 1-byte outputs: the same arithmetic as store_group, returning the G packed bytes instead
+// of storing them (conv_stream.cuh stages them in LDS to write 16 bytes per lane).
+template <int DST, int G, bool FAST>
+__device__ __forceinline__ unsigned pack_group(const int (&acc)[G], const float (&cp)[G], const float (&bs)[G],
+                                               const float (&sc)[G], bool relu, int rm) {
+  static_assert(DST == DFX_U8 || DST == DFX_S8, "1-byte outputs only");
+  unsigned pk = 0;
+#pragma unroll
+  for (int c = 0; c < G; ++c) {
+    float f;
+    if (FAST) f = __fmul_rn(__fadd_rn(__int2float_rn(acc[c]), bs[c]), sc[c]);
+    else f = __fmul_rn(acc_to_f32(acc[c], cp[c], bs[c]), sc[c]);
+    if (FAST && DST == DFX_U8) {
+      pk = __builtin_amdgcn_cvt_pk_u8_f32(f, c, pk);
+    } else {
+      const float fr = relu ? (FAST ? __builtin_fmaxf(f, 0.0f) : relu_x86(f)) : f;
+      const int v = FAST ? (int)__builtin_rintf(fr) : cvt_x86_rt(fr, rm);
+      const unsigned b = (DST == DFX_U8) ? sat_u8_bits(v) : ((unsigned)sat_s8(v) & 0xffu);
+      pk |= b << (8 * c);
+    }
+  }
+  return pk;
+}
+
 // FUSED = false is the unfused conv() overload (reference deepfusion.h:121-129): the same
 // loader / tile machinery and 3x3 MFMA ring, but the contraction is oriented
 // D0[px][oc] (A = input pixels, B = weights packed with the channel permutation, G ==

@@ -15,11 +15,17 @@
 //    of a step (2 x OCC or 2 x G KB, laid out by the host in exactly the order the
 //    kernel walks them) travel global -> registers -> LDS, double buffered: the loads
 //    of step t+1 are issued before the MFMAs of step t and written to the other
-//    of step t+2 are issued at the start of step t and written to the free buffer at
-//    the start of step t+1 (a full step in flight); one workgroup barrier per step.
-//    The four waves share every weight fragment, so L2 sees each weight byte once per
-//    128 pixels.  The next input chunk / next unit's tile is likewise fetched into
-//    registers during the last step before it is needed.
+//    of step t+3 are issued during step t and written during step t+1 into the third of
+//    three LDS buffers, so that step t+2's weights are already visible (one workgroup
+//    barrier per step) when a wave prefetches them.  The four waves share every weight
+//    fragment, so L2 sees each weight byte once per 128 pixels.  The next input chunk /
+//    next unit's tile is likewise fetched into registers during the last step before
+//    it is needed.
+//  * Inside a phase (one input chunk of conv0, or the 1x1 stage) every wave software-
+//    pipelines at k-block granularity: two fragment register sets; while the MFMAs of
+//    one k-block run, the fragments of the next one (possibly of the next step) are
+//    read from LDS and the weight pipeline's loads / LDS writes are issued, so a wave
+//    keeps the matrix pipe busy by itself.
 //  * The input halo tile sits in LDS one 64-channel chunk at a time ([position][64 B],
 //    stored as u8 - 128, 16-byte chunks XOR-swizzled like conv_mfma.cuh).
 //  * conv0 accumulates OCC 32-channel blocks at a time (D0[oc][px], weights = A
@@ -42,6 +48,8 @@ namespace dfx {
 constexpr int ST_THREADS = 256;
 constexpr int ST_M = 128;  // pixel slots per unit and PXB
 constexpr int ST_TQ = 4;   // tile granules (16 B) a thread stages with precomputed addresses
+constexpr int ST_STAGE = 32 * 144;  // per wave: 32 pixels x 128 output bytes (+16 pad), 1-byte outputs;
+                                   // the four staging areas alias the input tile (dead during the 1x1 stage)
 
 struct StreamGeom {
   int ni, thv, twv;     // unit = ni whole images (ni > 1 only if thv == oh && twv == ow) x thv x twv px
@@ -55,16 +63,17 @@ struct StreamGeom {
   int n_g1, ks2;        // conv1: groups of G column blocks; k-steps (pairs of oc blocks)
   int s0_steps;         // conv0 steps per unit
   int mid_stride;       // bytes per slot of the intermediate (32 * ocb + 16)
-  int off_tile, off_pxoff, off_mid, off_cst;  // LDS byte offsets (weight buffers at 0)
+  int off_tile, off_pxoff, off_mid, off_cst, off_stage;  // LDS byte offsets (weight buffers at 0)
   int fast;             // 1: the fast requant path is valid (host proof, see conv_mfma.cuh store_group)
 #ifdef DFX_STAMPS
   unsigned long long *prof;  // diagnostic build only: [workgroup][wave][16] cycle sums
 #endif
 };
 
-// The LDS load feeding an MFMA operand must not be overtaken / re-targeted while the
-// MFMA is in flight (see conv_mfma.cuh): every step loads all its fragments into
-// distinct registers, fences, issues the MFMAs, fences.
+// An LDS load must not target a register that a just-issued MFMA still has to read as
+// A/B operand (see conv_mfma.cuh).  The two fragment sets alternate per k-block and the
+// loads into a set are issued only after >= 2 MFMAs of the OTHER set have been issued
+// since the last MFMA that read it; sched_barrier keeps hipcc from re-mixing the groups.
 #define DFX_FENCE() __builtin_amdgcn_sched_barrier(0)
 #ifndef DFX_EXP
 #define DFX_EXP 0  // timing experiments (profiles/debug/exp_stream.sh): >0 builds produce wrong results
@@ -74,7 +83,7 @@ template <int OCC, int G, int PXB, int DST, bool FUSED>
 __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, StreamGeom g) {
   constexpr int ESZ = (DST == DFX_F32 || DST == DFX_S32) ? 4 : 1;
   constexpr int WB = FUSED ? (OCC > G ? OCC : G) : OCC;  // fragments per half step a buffer holds
-  constexpr int WBUF = 2 * WB * 1024;                    // bytes per weight buffer
+  constexpr int WBUF = 2 * WB * 1024;                    // bytes per weight buffer (three of them)
   constexpr int GA = 2 * OCC * 64, GB = 2 * G * 64;      // 16-byte granules per conv0 / conv1 step
   constexpr int NLD = (2 * WB * 64 + ST_THREADS - 1) / ST_THREADS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -99,24 +108,21 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
 
   // ---- weight stream: step t of a unit sits at granule woff(t) of the packed buffer ----
   v4i wreg[NLD];
+// (No branch around a load or an LDS write: hipcc would wait vmcnt(0) inside each one.
+// A step holds a power-of-two number of granules; surplus threads repeat a granule.)
 #define DFX_W_ISSUE(T)                                                                  \
   do {                                                                                  \
     const int t_ = (T);                                                                 \
     const int off_ = t_ < S0 ? t_ * GA : S0 * GA + (t_ - S0) * GB;                      \
-    const int cnt_ = t_ < S0 ? GA : GB;                                                 \
-    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                   \
-      const int q_ = tid + ST_THREADS * i;                                              \
-      if (DFX_EXP != 1 && q_ < cnt_) wreg[i] = wsrc[off_ + q_];                         \
-    }                                                                                   \
+    const int msk_ = (t_ < S0 ? GA : GB) - 1;                                           \
+    _Pragma("unroll") for (int i = 0; i < NLD; ++i)                                     \
+      if (DFX_EXP != 1) wreg[i] = wsrc[off_ + ((tid + ST_THREADS * i) & msk_)];         \
   } while (0)
 #define DFX_W_COMMIT(T, BUF)                                                            \
   do {                                                                                  \
-    const int cnt_ = (T) < S0 ? GA : GB;                                                \
+    const int msk_ = ((T) < S0 ? GA : GB) - 1;                                          \
     v4i *d_ = reinterpret_cast<v4i *>(smem + (BUF) * WBUF);                             \
-    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                                   \
-      const int q_ = tid + ST_THREADS * i;                                              \
-      if (q_ < cnt_) d_[q_] = wreg[i];                                                  \
-    }                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < NLD; ++i) d_[(tid + ST_THREADS * i) & msk_] = wreg[i]; \
   } while (0)
 
   // ---- tile staging: granule q = tid + 256 i covers LDS position q >> 2, 16-byte
@@ -136,6 +142,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
 
   // ---- input tile prefetch registers (first ST_TQ granules per thread) ----
   v4i tv[ST_TQ];
+  int tv_ok = 0;  // bit i: tv[i] is a real pixel granule (else padding)
 #define DFX_T_ISSUE(ORG, IY0, IX0, NIMG, ICC)                                           \
   do {                                                                                  \
     const int cb0_ = 64 * (ICC);                                                        \
@@ -146,16 +153,19 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
       const bool ok_ = q_ < tile_q && img_ < (NIMG) && iy_ >= 0 && iy_ < a.ih && ix_ >= 0 && \
                        ix_ < a.iw && cb0_ + 16 * (q_ & 3) < a.ic;                       \
       const int rel_ = ((img_ * a.ih + ly_) * a.iw + lx_) * a.ic + 16 * (q_ & 3);      \
-      tv[i] = v4i{0, 0, 0, 0};                                                          \
-      if (DFX_EXP != 6 && ok_) tv[i] = *reinterpret_cast<const v4i *>(a.src + ((ORG) + rel_ + cb0_)); \
+      /* branch-free: granules outside the image read src[0..15] and are zeroed */      \
+      const long long o_ = ok_ ? (ORG) + rel_ + cb0_ : 0ll;                             \
+      if (DFX_EXP != 6) tv[i] = *reinterpret_cast<const v4i *>(a.src + o_);             \
+      tv_ok = ok_ ? (tv_ok | (1 << i)) : (tv_ok & ~(1 << i)); /* zeroed at commit: no wait here */ \
     }                                                                                   \
   } while (0)
+/* granules beyond the tile go to a 16-byte dump slot right behind it */                  
 #define DFX_T_COMMIT()                                                                  \
   do {                                                                                  \
     _Pragma("unroll") for (int i = 0; i < ST_TQ; ++i) {                                 \
       const int q_ = tid + ST_THREADS * i, pos_ = q_ >> 2;                              \
-      if (q_ < tile_q)                                                                  \
-        *reinterpret_cast<v4i *>(tile + pos_ * 64 + 16 * ((q_ & 3) ^ chunk_swizzle<4>(pos_))) = tv[i] ^ x80; \
+      const int lo_ = q_ < tile_q ? pos_ * 64 + 16 * ((q_ & 3) ^ chunk_swizzle<4>(pos_)) : tile_q * 16; \
+      *reinterpret_cast<v4i *>(tile + lo_) = ((tv_ok >> i) & 1) ? tv[i] ^ x80 : x80;    \
     }                                                                                   \
   } while (0)
 
@@ -174,37 +184,78 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
   };
   const bool fast = g.fast != 0;
 #ifdef DFX_STAMPS
-  unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long prof_acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   DFX_STAMP(t_entry);
   using TT = std::true_type;
   using FF = std::false_type;
 
-  // Weight pipeline invariant at the start of step t: LDS buffer `buf` holds step t,
-  // wreg holds (in flight) step t+1.
-  int buf = 0;
+  // Weight pipeline invariant at the start of step t: LDS buffers cur and cur+1 (mod 3)
+  // hold steps t and t+1 (visible), wreg holds (in flight) step t+2.
+  int cur = 0;
   DFX_W_ISSUE(0);
   DFX_W_COMMIT(0, 0);
   DFX_W_ISSUE(1 % S);
+  DFX_W_COMMIT(1 % S, 1);
+  DFX_W_ISSUE(2 % S);
+  int tc = 2 % S, ti = 3 % S;  // the step wreg holds, the step to fetch next
   if (FUSED)
     for (int q = tid; q < 3 * OCP; q += ST_THREADS) cst0[q] = a.consts[q];  // visible after the first staging barrier
   bool tv_ready = false;  // tv holds the tile the next staging point needs
 #define DFX_STEP_WEIGHTS()                                                              \
   {                                                                                     \
-    int t1_ = t + 1; if (t1_ >= S) t1_ -= S;                                            \
-    int t2_ = t1_ + 1; if (t2_ >= S) t2_ -= S;                                          \
-    DFX_W_COMMIT(t1_, buf ^ 1);                                                         \
-    DFX_W_ISSUE(t2_);                                                                   \
+    int b2_ = cur + 2; if (b2_ >= 3) b2_ -= 3;                                          \
+    DFX_W_COMMIT(tc, b2_);                                                              \
+    DFX_W_ISSUE(ti);                                                                    \
+    if (++tc == S) tc = 0;                                                              \
+    if (++ti == S) ti = 0;                                                              \
   }
-#define DFX_STEP_END()  \
-  DFX_STAMP(b4);        \
-  if (DFX_EXP != 5) __syncthreads(); \
-  DFX_STAMP(b5);        \
-  DFX_ACC(3, b4 - b2);  \
-  DFX_ACC(4, b5 - b4);  \
-  DFX_ACC(2, b2 - b1);  \
-  buf ^= 1;             \
-  ++t
+#define DFX_STEP_END()                 \
+  if (DFX_EXP != 5) __syncthreads();   \
+  if (++cur == 3) cur = 0
+
+  constexpr int NM0 = OCC * PXB, NM1 = G * PXB;  // MFMAs per k-block
+  constexpr int NF0 = NM0 < 2 ? NM0 : 2, NF1 = NM1 < 2 ? NM1 : 2;
+  // conv0 k-block fragments: set s of fb / fw
+  v4i fb[2][PXB], fw[2][WB];
+  // loads the fragments of the phase's next k-block (index kb) into set SET from weight buffer WBI, half J
+#define DFX_LOAD0(SET, WBI, J)                                                          \
+  do {                                                                                  \
+    const int icbl_ = kbn == 2 ? (kb & 1) : 0;                                          \
+    _Pragma("unroll") for (int pb = 0; pb < PXB; ++pb) {                                \
+      const int P_ = Pb[pb] + tkh * g.lw + tkw;                                         \
+      fb[SET][pb] = *reinterpret_cast<const v4i *>(tile + P_ * 64 + 16 * ((2 * icbl_ + h) ^ chunk_swizzle<4>(P_))); \
+    }                                                                                   \
+    const unsigned char *wb_ = smem + (WBI) * WBUF + (J) * OCC * 1024 + lane16;         \
+    _Pragma("unroll") for (int r = 0; r < OCC; ++r)                                     \
+      fw[SET][r] = *reinterpret_cast<const v4i *>(wb_ + r * 1024);                      \
+    ++kb; /* a padding k-block (kb >= ns, zero weights) re-reads the last tap */        \
+    if ((kbn == 1 || (kb & 1) == 0) && kb < ns) {                                       \
+      if (++tkw == a.kw) { tkw = 0; ++tkh; }                                            \
+    }                                                                                   \
+  } while (0)
+#define DFX_MFMA0(SET, M0, M1)                                                          \
+  _Pragma("unroll") for (int m = (M0); m < (M1); ++m) {                                 \
+    const int r = m / PXB, pb = m % PXB;                                                \
+    if (DFX_EXP != 3)                                                                   \
+      acc[pb][r] = FUSED ? mfma_i8(fw[SET][r], fb[SET][pb], acc[pb][r])   /* D0[oc][px] */ \
+                         : mfma_i8(fb[SET][pb], fw[SET][r], acc[pb][r]);  /* D0[px][oc] */ \
+  }
+#define DFX_LOAD1(SET, WBI, J)                                                          \
+  do {                                                                                  \
+    const int blk_ = min(kb, g.ocb - 1); /* a padding k-block has zero weights */       \
+    _Pragma("unroll") for (int pb = 0; pb < PXB; ++pb)                                  \
+      fb[SET][pb] = *reinterpret_cast<const v4i *>(my_mid[pb] + blk_ * 32);             \
+    const unsigned char *wb_ = smem + (WBI) * WBUF + (J) * G * 1024 + lane16;           \
+    _Pragma("unroll") for (int cc = 0; cc < G; ++cc)                                    \
+      fw[SET][cc] = *reinterpret_cast<const v4i *>(wb_ + cc * 1024);                    \
+    ++kb;                                                                               \
+  } while (0)
+#define DFX_MFMA1(SET, M0, M1)                                                          \
+  _Pragma("unroll") for (int m = (M0); m < (M1); ++m) {                                 \
+    const int cc = m / PXB, pb = m % PXB;                                               \
+    if (DFX_EXP != 3) acc1[pb][cc] = mfma_i8(fb[SET][pb], fw[SET][cc], acc1[pb][cc]);   \
+  }
 
   for (int unit = blockIdx.x; unit < g.total_units; unit += gridDim.x) {
     DFX_STAMP(u0);
@@ -229,7 +280,6 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
       my_mid[pb] = mid + slot * g.mid_stride + h * 16;
     }
 
-    int t = 0;
     for (int occ = 0; occ < g.n_occ; ++occ) {
       v16i acc[PXB][OCC];
 #pragma unroll
@@ -243,10 +293,9 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
       if (!FUSED) {
 #pragma unroll
         for (int cc = 0; cc < OCC; ++cc) {
-          const int c = min(chb0 + cc, OCP - 1);
-          cp0[cc] = fast ? 0 : comp0[c];
-          bs0[cc] = bias0[c];
-          sc0[cc] = scale0[c];
+          cp0[cc] = fast ? 0 : comp0[chb0 + cc];
+          bs0[cc] = bias0[chb0 + cc];
+          sc0[cc] = scale0[chb0 + cc];
         }
       }
       for (int icc = 0; icc < g.n_icc; ++icc) {
@@ -255,6 +304,9 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
         //      A single-chunk input stays in LDS for all output chunks of the unit. ----
         if (g.n_icc > 1 || occ == 0) {
           DFX_STAMP(s0);
+          // the 1-byte store staging area aliases the tile: every wave must be out of the
+          // previous unit's epilogue before the new tile lands
+          if (FUSED && ESZ == 1 && G == 4 && occ == 0 && icc == 0) __syncthreads();
           if (!tv_ready) DFX_T_ISSUE(ug.org, ug.iy0, ug.ix0, ug.nimg, icc);
           DFX_T_COMMIT();
           tv_ready = false;
@@ -276,12 +328,35 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
           DFX_ACC(0, s1 - s0);
         }
         const int kbn = min(2, g.icb - 2 * icc);  // 32-channel blocks in this chunk
-        const int ntap = a.kh * a.kw;
-        const int ns = ntap * kbn, ns2 = (ns + 1) >> 1;
-        int tkh = 0, tkw = 0;  // tap of k-block s (kept incrementally)
+        const int ns = a.kh * a.kw * kbn, ns2 = (ns + 1) >> 1;  // k-blocks, steps
+        int kb = 0, tkh = 0, tkw = 0;  // next k-block to load and its tap
+        DFX_STAMP(p0);
+        DFX_LOAD0(0, cur, 0);  // phase prologue (exposed): the first k-block's fragments
+        DFX_FENCE();
         for (int s2 = 0; s2 < ns2; ++s2) {
-          DFX_STAMP(b0);
-          DFX_STAMP(b1);
+          // k-block (s2, 0) from set 0, while set 1 <- (s2, 1)
+          DFX_STAMP(x0);
+          DFX_MFMA0(0, 0, NF0);
+          DFX_FENCE();
+          DFX_STAMP(x1);
+          DFX_LOAD0(1, cur, 1);
+          DFX_FENCE();
+          DFX_STAMP(x2);
+          DFX_MFMA0(0, NF0, NM0);
+          DFX_FENCE();
+          // k-block (s2, 1) from set 1, while set 0 <- (s2 + 1, 0) of the next buffer, and
+          // the weight pipeline / tile prefetch move on
+          DFX_STAMP(x3);
+          DFX_MFMA0(1, 0, NF0);
+          DFX_FENCE();
+          DFX_STAMP(x4);
+          if (s2 + 1 < ns2) {
+            int nb_ = cur + 1; if (nb_ == 3) nb_ = 0;
+            DFX_LOAD0(0, nb_, 0);
+          }
+          DFX_STAMP(x5);
+          DFX_STEP_WEIGHTS();
+          DFX_STAMP(x6);
           if (s2 == ns2 - 1) {  // last step before the next staging point: fetch its tile now
             if (g.n_icc > 1 && (icc + 1 < g.n_icc || occ + 1 < g.n_occ)) {
               DFX_T_ISSUE(ug.org, ug.iy0, ug.ix0, ug.nimg, icc + 1 < g.n_icc ? icc + 1 : 0);
@@ -292,47 +367,19 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
               tv_ready = true;
             }
           }
-          const unsigned char *wb = smem + buf * WBUF;
-          v4i fb[2][PXB], fw[2][OCC];
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int s = 2 * s2 + j;
-            const int icbl = kbn == 2 ? j : 0;
-#pragma unroll
-            for (int pb = 0; pb < PXB; ++pb) {
-              const int P = Pb[pb] + tkh * g.lw + tkw;
-              if (DFX_EXP == 4) { fb[j][pb] = v4i{P, P, P, P}; } else
-              fb[j][pb] = *reinterpret_cast<const v4i *>(tile + P * 64 + 16 * ((2 * icbl + h) ^ chunk_swizzle<4>(P)));
-            }
-#pragma unroll
-            for (int r = 0; r < OCC; ++r)
-              if (DFX_EXP == 4) { fw[j][r] = v4i{lane16, buf, r, j}; } else
-              fw[j][r] = *reinterpret_cast<const v4i *>(wb + (j * OCC + r) * 1024 + lane16);
-            // advance the tap after the chunk's last k-block of it; a padding k-block
-            // (s >= ns, zero weights) re-reads the last tap
-            if ((kbn == 1 || j == 1) && s + 1 < ns) {
-              if (++tkw == a.kw) { tkw = 0; ++tkh; }
-            }
-          }
           DFX_FENCE();
-          DFX_STAMP(b2);  // (diagnostic builds: waits for the fragments)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int r = 0; r < OCC; ++r)
-#pragma unroll
-              for (int pb = 0; pb < PXB; ++pb)
-                if (DFX_EXP != 3)
-                  acc[pb][r] = FUSED ? mfma_i8(fw[j][r], fb[j][pb], acc[pb][r])   // D0[oc][px]
-                                     : mfma_i8(fb[j][pb], fw[j][r], acc[pb][r]);  // D0[px][oc]
-            DFX_FENCE();
-            if (j == 0) {  // the weight pipeline's VALU / LDS-write work runs under the first MFMAs
-              DFX_STEP_WEIGHTS();
-              DFX_FENCE();
-            }
-          }
+          DFX_STAMP(x7);
+          DFX_MFMA0(1, NF0, NM0);
+          DFX_FENCE();
+          DFX_STAMP(x8);
           DFX_STEP_END();
+          DFX_STAMP(x9);
+          DFX_ACC(10, x1 - x0); DFX_ACC(11, x2 - x1); DFX_ACC(12, x3 - x2); DFX_ACC(13, x4 - x3);
+          DFX_ACC(14, x5 - x4); DFX_ACC(15, x6 - x5); DFX_ACC(16, x7 - x6); DFX_ACC(17, x8 - x7);
+          DFX_ACC(18, x9 - x8); DFX_ACC(19, 1);
         }
+        DFX_STAMP(p1);
+        DFX_ACC(1, p1 - p0);
       }
       DFX_STAMP(e0);
       if constexpr (FUSED) {
@@ -367,7 +414,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
             }
             pkv[q] = (int)(pk ^ 0x80808080u);
           }
-          *reinterpret_cast<v4i *>(my_mid[pb] + (occ * OCC + r) * 32) = pkv;
+          if (DFX_EXP != 2) *reinterpret_cast<v4i *>(my_mid[pb] + (occ * OCC + r) * 32) = pkv;
         }
       } else {
         // ---- unfused: typed store; lane owns channels 32*OCC*occ + OCC*l31 + {0..OCC-1} ----
@@ -407,9 +454,14 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
     }
 
     if constexpr (FUSED) {
-      // ---- conv1 over mid, G column blocks at a time ----
+      // ---- conv1 over mid, G column blocks at a time; the fragment pipeline runs through
+      //      the groups (mid and every weight step of the unit are already in LDS) ----
       const bool relu = a.relu1 || DST == DFX_U8;
+      int kb = 0;  // next k-block (= 32-channel block of mid) to load
+      DFX_LOAD1(0, cur, 0);  // phase prologue
+      DFX_FENCE();
       for (int g1 = 0; g1 < g.n_g1; ++g1) {
+        DFX_STAMP(q0);
         v16i acc1[PXB][G];
 #pragma unroll
         for (int pb = 0; pb < PXB; ++pb)
@@ -427,46 +479,33 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
           zf[cc] = 0.0f;
         }
         for (int s2 = 0; s2 < g.ks2; ++s2) {
-          DFX_STAMP(b0);
-          DFX_STAMP(b1);
+          DFX_MFMA1(0, 0, NF1);
+          DFX_FENCE();
+          DFX_LOAD1(1, cur, 1);
+          DFX_FENCE();
+          DFX_MFMA1(0, NF1, NM1);
+          DFX_FENCE();
+          DFX_MFMA1(1, 0, NF1);
+          DFX_FENCE();
+          if (s2 + 1 < g.ks2 || g1 + 1 < g.n_g1) {
+            if (s2 + 1 == g.ks2) kb = 0;  // next group starts over on mid
+            int nb_ = cur + 1; if (nb_ == 3) nb_ = 0;
+            DFX_LOAD1(0, nb_, 0);
+          }
+          DFX_STEP_WEIGHTS();
           if (g1 + 1 == g.n_g1 && s2 + 1 == g.ks2 && has_next) {  // next unit's first tile
             const UnitGeo nx = unit_geo(unit + gridDim.x);
             DFX_T_ISSUE(nx.org, nx.iy0, nx.ix0, nx.nimg, 0);
             tv_ready = true;
           }
-          const unsigned char *wb = smem + buf * WBUF;
-          v4i fa[2][PXB], fw[2][G];
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int blk = min(2 * s2 + j, g.ocb - 1);  // a padding k-block has zero weights
-#pragma unroll
-            for (int pb = 0; pb < PXB; ++pb)
-              if (DFX_EXP == 4) { fa[j][pb] = v4i{blk, lane16, pb, j}; } else
-              fa[j][pb] = *reinterpret_cast<const v4i *>(my_mid[pb] + blk * 32);
-#pragma unroll
-            for (int cc = 0; cc < G; ++cc)
-              if (DFX_EXP == 4) { fw[j][cc] = v4i{lane16, buf, cc, j}; } else
-              fw[j][cc] = *reinterpret_cast<const v4i *>(wb + (j * G + cc) * 1024 + lane16);
-          }
           DFX_FENCE();
-          DFX_STAMP(b2);
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int cc = 0; cc < G; ++cc)
-#pragma unroll
-              for (int pb = 0; pb < PXB; ++pb)
-                if (DFX_EXP != 3) acc1[pb][cc] = mfma_i8(fa[j][pb], fw[j][cc], acc1[pb][cc]);
-            DFX_FENCE();
-            if (j == 0) {
-              DFX_STEP_WEIGHTS();
-              DFX_FENCE();
-            }
-          }
+          DFX_MFMA1(1, NF1, NM1);
+          DFX_FENCE();
           DFX_STEP_END();
         }
         DFX_STAMP(e2);
-        if (chb < a.oc1) {
+        DFX_ACC(2, e2 - q0);
+        if ((ESZ == 1 && G == 4) || chb < a.oc1) {
           unsigned char *dst_b = reinterpret_cast<unsigned char *>(a.dst);
           const unsigned chbE = (unsigned)chb * ESZ;
           auto emit1 = [&](auto fast_tag, auto check_tag) {
@@ -488,7 +527,35 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
                 }
               }
           };
+          // 1-byte outputs with 4 column blocks: a dword store per pixel costs as much issue
+          // time as a 16-byte one, so the wave transposes its 32 x 128 bytes through LDS
+          // and writes 16 bytes per lane (4 stores per pixel block instead of 16)
+          auto emit1s = [&](auto fast_tag) {
+            if constexpr (ESZ == 1 && G == 4) {
+              unsigned char *stg = smem + g.off_stage + wave * ST_STAGE;
+#pragma unroll
+              for (int pb = 0; pb < PXB; ++pb) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                  int v[G];
+#pragma unroll
+                  for (int cc = 0; cc < G; ++cc) v[cc] = acc1[pb][cc][e] + cp[cc];
+                  const unsigned pk = pack_group<DST, G, decltype(fast_tag)::value>(v, zf, bs, sc, relu, a.rm1);
+                  *reinterpret_cast<unsigned *>(stg + (8 * (e >> 2) + (e & 3) + 4 * h) * 144 + 4 * l31) = pk;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  const int c = lane + 64 * k, px = c >> 3, c16 = c & 7;
+                  const unsigned off = pxoff[32 * (wave * PXB + pb) + px];
+                  const v4i val = *reinterpret_cast<const v4i *>(stg + px * 144 + 16 * c16);
+                  if (off != 0xffffffffu && 128 * g1 + 16 * c16 < a.oc1)
+                    DFX_STORE(reinterpret_cast<v4i *>(dst_b + (size_t)(off + 128 * g1 + 16 * c16)), val);
+                }
+              }
+            }
+          };
           if (DFX_EXP == 2) { if (acc1[0][0][0] == 0x12345678) emit1(TT{}, TT{}); }
+          else if (ESZ == 1 && G == 4) { if (fast) emit1s(TT{}); else emit1s(FF{}); }
           else if (fast) { if (full) emit1(TT{}, FF{}); else emit1(TT{}, TT{}); }
           else      { if (full) emit1(FF{}, FF{}); else emit1(FF{}, TT{}); }
         }
@@ -504,8 +571,8 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
   {
     DFX_STAMP(t_end);
     if (lane == 0) {
-      unsigned long long *o = g.prof + ((size_t)blockIdx.x * 4 + wave) * 16;
-      for (int k = 0; k < 9; ++k) o[k] = prof_acc[k];
+      unsigned long long *o = g.prof + ((size_t)blockIdx.x * 4 + wave) * 24;
+      for (int k = 0; k < 24; ++k) o[k] = prof_acc[k];
       o[9] = t_end - t_entry;
     }
   }
@@ -516,6 +583,10 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
 #undef DFX_T_COMMIT
 #undef DFX_STEP_WEIGHTS
 #undef DFX_STEP_END
+#undef DFX_LOAD0
+#undef DFX_MFMA0
+#undef DFX_LOAD1
+#undef DFX_MFMA1
 }
 
 }  // namespace dfx

@@ -324,7 +324,8 @@ static bool pick_stream_geometry(const dfx_conv_desc &d, int OCC, int G, int PXB
   g.s0_steps = s0 * g.n_occ;
   const int WB = fused ? std::max(OCC, G) : OCC;
   const size_t cst_bytes = fused ? round16((size_t)3 * 32 * g.ocb * 4) : 0;
-  const size_t fixed = (size_t)2 * 2 * WB * 1024 + 4 * M + (fused ? (size_t)M * g.mid_stride : 0) + cst_bytes;
+  const size_t stage_bytes = (fused && G == 4 && dt_size(d.dst_dt) == 1) ? (size_t)4 * ST_STAGE : 0;  // 4 waves
+  const size_t fixed = (size_t)3 * 2 * WB * 1024 + 4 * M + (fused ? (size_t)M * g.mid_stride : 0) + cst_bytes;
   const size_t lds_max = 163840;
   // index ranges the kernel keeps in 32 bits / packed fields
   // (dst byte offsets are 32-bit in the kernel's pixel table)
@@ -335,7 +336,7 @@ static bool pick_stream_geometry(const dfx_conv_desc &d, int OCC, int G, int PXB
     const int lh = (thv - 1) * d.sh + d.kh, lw = (twv - 1) * d.sw + d.kw;
     if (lh >= 1024 || lw >= 1024) return;
     const long long npos = (long long)ni * lh * lw;
-    if (fixed + (size_t)npos * 64 > lds_max) return;
+    if (fixed + std::max((size_t)npos * 64 + 16, stage_bytes) > lds_max) return;
     const double groups = (double)((d.bs + ni - 1) / ni);
     const double units = groups * ((d.oh + thv - 1) / thv) * ((d.ow + twv - 1) / twv);
     const double util = (double)d.bs * d.oh * d.ow / (units * M);           // filled pixel slots
@@ -355,10 +356,12 @@ static bool pick_stream_geometry(const dfx_conv_desc &d, int OCC, int G, int PXB
   g.uy = (d.oh + g.thv - 1) / g.thv;
   g.ux = (d.ow + g.twv - 1) / g.twv;
   g.total_units = (d.bs + g.ni - 1) / g.ni * g.uy * g.ux;
-  g.off_tile = 2 * 2 * WB * 1024;
-  g.off_pxoff = (int)round16((size_t)g.off_tile + (size_t)g.npos * 64);
+  g.off_tile = 3 * 2 * WB * 1024;  // three weight buffers
+  // +16: the staging dump slot; the 1-byte store staging areas alias the tile
+  g.off_pxoff = (int)round16((size_t)g.off_tile + std::max((size_t)g.npos * 64 + 16, stage_bytes));
   g.off_mid = g.off_pxoff + 4 * M;
   g.off_cst = g.off_mid + (fused ? M * g.mid_stride : 0);
+  g.off_stage = g.off_tile;
   lds = g.off_cst + (int)cst_bytes;
   return true;
 }
@@ -436,7 +439,7 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
       }
     }
     // Two pixel blocks per wave halve the LDS fragment traffic per MFMA but double the unit:
-    // taken when the units still fill the machine twice over, and when it fits LDS.
+    // taken when the units still fill the machine twice over and two workgroups still share a CU.
     int ncu = 256;
     {
       int dev = 0;
@@ -446,7 +449,7 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     h->pxb = 2;
     if (const char *e = getenv("DFX_STREAM_PXB")) h->pxb = atoi(e) == 1 ? 1 : 2;  // tuning aid
     stream_ok = h->pxb == 2 && pick_stream_geometry(d, h->occ, h->G, 2, h->sgeom, h->lds) &&
-                (h->sgeom.total_units >= 4 * ncu || getenv("DFX_STREAM_PXB"));
+                ((h->sgeom.total_units >= 4 * ncu && h->lds <= 81920) || getenv("DFX_STREAM_PXB"));
     if (!stream_ok) {
       h->pxb = 1;
       stream_ok = pick_stream_geometry(d, h->occ, h->G, 1, h->sgeom, h->lds);
@@ -473,8 +476,8 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     if (per_cu < 1) per_cu = 1;
     h->grid = std::min(h->sgeom.total_units, prop.multiProcessorCount * per_cu);
 #ifdef DFX_STAMPS
-    if (hipMalloc((void **)&h->d_prof, (size_t)h->grid * 64 * 8) != hipSuccess ||
-        hipMemset(h->d_prof, 0, (size_t)h->grid * 64 * 8) != hipSuccess) {
+    if (hipMalloc((void **)&h->d_prof, (size_t)h->grid * 96 * 8) != hipSuccess ||
+        hipMemset(h->d_prof, 0, (size_t)h->grid * 96 * 8) != hipSuccess) {
       delete h;
       return fail(DFX_ERR_HIP, "conv_create: cannot allocate the stamp buffer");
     }
@@ -855,7 +858,7 @@ int dfx_conv_query(const dfx_conv_t *h, dfx_conv_info *info) {
 // diagnostic build only: copies the [grid][8 waves][8] stamp sums of the last launch
 int dfx_debug_read_stamps(dfx_conv_t *h, unsigned long long *out, int max_entries) {
   if (!h || !h->d_prof) return fail(DFX_ERR_STATE, "no stamps");
-  int n = h->grid * (h->variant == DFX_VARIANT_MFMA_STREAM ? 64 : 256);
+  int n = h->grid * (h->variant == DFX_VARIANT_MFMA_STREAM ? 96 : 256);
   if (n > max_entries) n = max_entries;
   HIP_TRY(hipMemcpy(out, h->d_prof, (size_t)n * 8, hipMemcpyDeviceToHost));
   return n;

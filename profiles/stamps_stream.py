@@ -35,16 +35,23 @@ torch.cuda.synchronize()
 L = capi.lib()
 L.dfx_debug_read_stamps.restype = ctypes.c_int
 L.dfx_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
-buf = np.zeros(info.grid * 64, dtype=np.uint64)
+buf = np.zeros(info.grid * 96, dtype=np.uint64)
 n = L.dfx_debug_read_stamps(op._h, buf.ctypes.data_as(ctypes.c_void_p), buf.size)
-p = buf[:n].reshape(info.grid, 4, 16).astype(np.float64)
+p = buf[:n].reshape(info.grid, 4, 24).astype(np.float64)
 print(wl, desc, "kernel", info.kernel_name.decode(), "grid", info.grid, "lds", info.lds_bytes)
 units = p[..., 8]
 print("units per workgroup: mean %.2f min %.0f max %.0f" % (units.mean(), units.min(), units.max()))
-names = ["tile staging (+barrier)", "step begin (weights commit/issue)", "fragment LDS reads", "MFMA issue",
-         "step barrier", "conv0 epilogue", "conv1 epilogue + stores", "whole unit"]
+names = ["tile staging (+barrier)", "conv0 phases (steps)", "conv1 steps", "-",
+         "-", "conv0 epilogue", "conv1 epilogue + stores", "whole unit"]
 tot = p[..., 7].sum()
 for k, nm in enumerate(names):
+    if nm == '-':
+        continue
     print("%-36s %10.0f cycles/unit/wave %6.1f%%" % (nm, p[..., k].sum() / units.sum(), 100 * p[..., k].sum() / tot))
 life = p[..., 9]
 print("wave lifetime: mean %.0f min %.0f max %.0f cycles (s_memtime ~100 MHz x21?)" % (life.mean(), life.min(), life.max()))
+steps = p[..., 19].sum()
+for k, nm in zip(range(10, 19), ["MFMA set0 first 2", "issue LDS loads set1", "MFMA set0 rest", "MFMA set1 first 2 (waits set1)",
+                                 "issue LDS loads next set0", "weights commit + issue", "tile prefetch issue",
+                                 "MFMA set1 rest", "barrier"]):
+    print("conv0 step: %-34s %8.0f cycles/step" % (nm, p[..., k].sum() / steps))
