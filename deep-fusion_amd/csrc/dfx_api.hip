@@ -475,6 +475,7 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     int per_cu = mfma_dispatch(h, nullptr, 2);
     if (per_cu < 1) per_cu = 1;
     h->grid = std::min(h->sgeom.total_units, prop.multiProcessorCount * per_cu);
+    if (const char *e = getenv("DFX_STREAM_GRID")) h->grid = std::max(1, std::min(h->grid, atoi(e)));  // testing aid
 #ifdef DFX_STAMPS
     if (hipMalloc((void **)&h->d_prof, (size_t)h->grid * 96 * 8) != hipSuccess ||
         hipMemset(h->d_prof, 0, (size_t)h->grid * 96 * 8) != hipSuccess) {

@@ -119,6 +119,37 @@ def test_stream_variant_exact_requant_path(hip, oracle, monkeypatch):
         hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), case.ident())
 
 
+@pytest.mark.parametrize("grid", ["1", "3"])
+def test_stream_variant_many_units_per_workgroup(hip, oracle, monkeypatch, grid):
+    """DFX_STREAM_GRID caps the grid so that every workgroup walks many units: covers the
+    cross-unit tile / weight prefetch and the unit-to-unit LDS reuse."""
+    monkeypatch.setenv("DFX_STREAM_GRID", grid)
+    for case in STREAM_SHAPES + [C.CONFIG3_SMALL, C.unfused(C.CONFIG2), replace(C.CONFIG3_SMALL, dst_dt=C.U8, wide=True)]:
+        data = C.generate(case)
+        got, info = hip.hip_conv(case, data, force_variant=hip.dfa.VARIANT_MFMA_STREAM)
+        assert info.grid <= int(grid)
+        hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), case.ident())
+
+
+STREAM_FULL = [
+    C.ConvCase("res3", 128, 128, 28, 28, 128, 512, dst_dt=C.U8),
+    C.ConvCase("res3w", 32, 128, 28, 28, 128, 512, dst_dt=C.S32, wide=True, per_channel0=True, per_channel1=True),
+    C.ConvCase("res4", 64, 256, 14, 14, 256, 1024, dst_dt=C.U8),
+    C.ConvCase("res5", 32, 512, 7, 7, 512, 2048, dst_dt=C.S8, relu1=False),
+    C.ConvCase("res3s2", 32, 128, 56, 56, 128, 512, stride=(2, 2), dst_dt=C.F32),
+    C.unfused(C.ConvCase("vgg128", 8, 128, 56, 56, 128, 0, dst_dt=C.U8)),
+]
+
+
+@pytest.mark.parametrize("case", STREAM_FULL, ids=lambda c: c.ident())
+def test_stream_variant_full_size(hip, oracle, case):
+    """ResNet-50 res3..res5-style blocks at (near) bench size: more units than workgroups."""
+    data = C.generate(case)
+    got, info = hip.hip_conv(case, data)
+    assert info.variant == hip.dfa.VARIANT_MFMA_STREAM, info.kernel_name
+    hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), info.kernel_name.decode())
+
+
 def test_auto_variant_prefers_mfma(hip):
     """shapes outside the resident-weight kernel go to the streamed MFMA kernel, not the scalar one."""
     for case in STREAM_SHAPES[:4]:
