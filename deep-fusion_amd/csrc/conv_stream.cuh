@@ -48,6 +48,7 @@ namespace dfx {
 constexpr int ST_THREADS = 256;
 constexpr int ST_M = 128;  // pixel slots per unit and PXB
 constexpr int ST_TQ = 4;   // tile granules (16 B) a thread stages with precomputed addresses
+constexpr int ST_POS = 64;  // LDS bytes per halo-tile position (16-byte chunks XOR-swizzled by position)
 constexpr int ST_STAGE = 32 * 144;  // per wave: 32 pixels x 128 output bytes (+16 pad), 1-byte outputs;
                                    // the four staging areas alias the input tile (dead during the 1x1 stage)
 
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
   // ---- tile staging: granule q = tid + 256 i covers LDS position q >> 2, 16-byte
   //      chunk q & 3; its image / row / column inside the halo tile never change ----
   const int lhw = g.lh * g.lw;
+  const int row_skip = g.lw - a.kw;  // positions from the last tap of a kernel row to the first of the next
   const int tile_q = g.npos * 4;
   int tq_pos[ST_TQ];  // img << 20 | ly << 10 | lx of the granule's position
 #pragma unroll
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
   do {                                                                                  \
     _Pragma("unroll") for (int i = 0; i < ST_TQ; ++i) {                                 \
       const int q_ = tid + ST_THREADS * i, pos_ = q_ >> 2;                              \
-      const int lo_ = q_ < tile_q ? pos_ * 64 + 16 * ((q_ & 3) ^ chunk_swizzle<4>(pos_)) : tile_q * 16; \
+      const int lo_ = q_ < tile_q ? pos_ * ST_POS + 16 * ((q_ & 3) ^ chunk_swizzle<4>(pos_)) : g.npos * ST_POS; \
       *reinterpret_cast<v4i *>(tile + lo_) = ((tv_ok >> i) & 1) ? tv[i] ^ x80 : x80;    \
     }                                                                                   \
   } while (0)
@@ -221,17 +223,20 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
   // loads the fragments of the phase's next k-block (index kb) into set SET from weight buffer WBI, half J
 #define DFX_LOAD0(SET, WBI, J)                                                          \
   do {                                                                                  \
-    const int icbl_ = kbn == 2 ? (kb & 1) : 0;                                          \
+    /* wave-uniform: this k-block's tap (in positions) and 32-channel half */            \
+    const int tp_ = __builtin_amdgcn_readfirstlane(toff);                               \
+    const int ch_ = __builtin_amdgcn_readfirstlane((kbn == 2 && (kb & 1)) ? 2 : 0);     \
     _Pragma("unroll") for (int pb = 0; pb < PXB; ++pb) {                                \
-      const int P_ = Pb[pb] + tkh * g.lw + tkw;                                         \
-      fb[SET][pb] = *reinterpret_cast<const v4i *>(tile + P_ * 64 + 16 * ((2 * icbl_ + h) ^ chunk_swizzle<4>(P_))); \
+      const int P_ = fbase[pb] + tp_;                                                   \
+      fb[SET][pb] = *reinterpret_cast<const v4i *>(tile + P_ * ST_POS + 16 * ((ch_ ^ h) ^ chunk_swizzle<4>(P_))); \
     }                                                                                   \
     const unsigned char *wb_ = smem + (WBI) * WBUF + (J) * OCC * 1024 + lane16;         \
     _Pragma("unroll") for (int r = 0; r < OCC; ++r)                                     \
       fw[SET][r] = *reinterpret_cast<const v4i *>(wb_ + r * 1024);                      \
     ++kb; /* a padding k-block (kb >= ns, zero weights) re-reads the last tap */        \
     if ((kbn == 1 || (kb & 1) == 0) && kb < ns) {                                       \
-      if (++tkw == a.kw) { tkw = 0; ++tkh; }                                            \
+      toff += 1;                                                                        \
+      if (++tkw == a.kw) { tkw = 0; toff += row_skip; }                                 \
     }                                                                                   \
   } while (0)
 #define DFX_MFMA0(SET, M0, M1)                                                          \
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
     const bool has_next = unit + (int)gridDim.x < g.total_units;
     const bool full = npx == ST_M * PXB;  // every slot holds a pixel: the stores need no predicate
     // this lane's pixel slots (conv0 column / conv1 row), one per pixel block
-    int Pb[PXB];
+    int fbase[PXB];  // the slot's input position (tap 0) in the halo tile
     unsigned char *my_mid[PXB];
 #pragma unroll
     for (int pb = 0; pb < PXB; ++pb) {
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
       const int pc = min(slot, npx - 1);
       const int img = pc / (thc * twc), r = pc - img * (thc * twc);
       const int ty = r / twc, tx = r - ty * twc;
-      Pb[pb] = img * lhw + ty * a.sh * g.lw + tx * a.sw;
+      fbase[pb] = img * lhw + ty * a.sh * g.lw + tx * a.sw;
       if (h == 0)
         pxoff[slot] = slot < npx ? (unsigned)(((ug.n0 + img) * a.oh + ug.y0 + ty) * a.ow + ug.x0 + tx) * row_bytes
                                  : 0xffffffffu;
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
             if (ok)
               v = *reinterpret_cast<const v4i *>(
                   a.src + (ug.org + (long long)((img * a.ih + ly) * a.iw + lx) * a.ic + 16 * j + cb0));
-            *reinterpret_cast<v4i *>(tile + pos * 64 + 16 * (j ^ chunk_swizzle<4>(pos))) = v ^ x80;
+            *reinterpret_cast<v4i *>(tile + pos * ST_POS + 16 * (j ^ chunk_swizzle<4>(pos))) = v ^ x80;
           }
           __syncthreads();
           DFX_STAMP(s1);
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
         }
         const int kbn = min(2, g.icb - 2 * icc);  // 32-channel blocks in this chunk
         const int ns = a.kh * a.kw * kbn, ns2 = (ns + 1) >> 1;  // k-blocks, steps
-        int kb = 0, tkh = 0, tkw = 0;  // next k-block to load and its tap
+        int kb = 0, tkw = 0, toff = 0;  // next k-block to load, its tap column and tap offset in positions
         DFX_STAMP(p0);
         DFX_LOAD0(0, cur, 0);  // phase prologue (exposed): the first k-block's fragments
         DFX_FENCE();

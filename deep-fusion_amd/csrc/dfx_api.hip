@@ -336,7 +336,7 @@ static bool pick_stream_geometry(const dfx_conv_desc &d, int OCC, int G, int PXB
     const int lh = (thv - 1) * d.sh + d.kh, lw = (twv - 1) * d.sw + d.kw;
     if (lh >= 1024 || lw >= 1024) return;
     const long long npos = (long long)ni * lh * lw;
-    if (fixed + std::max((size_t)npos * 64 + 16, stage_bytes) > lds_max) return;
+    if (fixed + std::max((size_t)npos * ST_POS + 16, stage_bytes) > lds_max) return;
     const double groups = (double)((d.bs + ni - 1) / ni);
     const double units = groups * ((d.oh + thv - 1) / thv) * ((d.ow + twv - 1) / twv);
     const double util = (double)d.bs * d.oh * d.ow / (units * M);           // filled pixel slots
@@ -358,7 +358,7 @@ static bool pick_stream_geometry(const dfx_conv_desc &d, int OCC, int G, int PXB
   g.total_units = (d.bs + g.ni - 1) / g.ni * g.uy * g.ux;
   g.off_tile = 3 * 2 * WB * 1024;  // three weight buffers
   // +16: the staging dump slot; the 1-byte store staging areas alias the tile
-  g.off_pxoff = (int)round16((size_t)g.off_tile + std::max((size_t)g.npos * 64 + 16, stage_bytes));
+  g.off_pxoff = (int)round16((size_t)g.off_tile + std::max((size_t)g.npos * ST_POS + 16, stage_bytes));
   g.off_mid = g.off_pxoff + 4 * M;
   g.off_cst = g.off_mid + (fused ? M * g.mid_stride : 0);
   g.off_stage = g.off_tile;
