@@ -397,6 +397,16 @@ static int mfma_dispatch(dfx_conv *h, hipStream_t s, int mode) {
   return -1;
 }
 
+// releases everything a conv handle owns (also used on dfx_conv_create's failure paths)
+static void conv_release(dfx_conv *h) {
+  if (!h) return;
+  if (h->host_stream) (void)hipStreamDestroy(h->host_stream);
+  (void)hipFree(h->d_wei); (void)hipFree(h->d_wei1); (void)hipFree(h->d_consts);
+  (void)hipFree(h->d_src); (void)hipFree(h->d_dst); (void)hipFree(h->d_queue);
+  (void)hipFree(h->d_prof);
+  delete h;
+}
+
 extern "C" {
 
 int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
@@ -423,7 +433,7 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
   bool want_mfma = mfma_eligible(d) && d.force_variant != DFX_VARIANT_GENERIC &&
                    d.force_variant != DFX_VARIANT_MFMA_STREAM;
   if ((d.force_variant == DFX_VARIANT_MFMA_FUSED || d.force_variant == DFX_VARIANT_MFMA_CONV) && !mfma_eligible(d)) {
-    delete h;
+    conv_release(h);
     return fail(DFX_ERR_UNSUPPORTED, "conv_create: shape not covered by the MFMA variant");
   }
   const bool want_stream = !want_mfma && d.force_variant != DFX_VARIANT_GENERIC;
@@ -455,7 +465,7 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
       stream_ok = pick_stream_geometry(d, h->occ, h->G, 1, h->sgeom, h->lds);
     }
     if (!stream_ok && d.force_variant == DFX_VARIANT_MFMA_STREAM) {
-      delete h;
+      conv_release(h);
       return fail(DFX_ERR_UNSUPPORTED, "conv_create: shape does not fit the streamed MFMA variant");
     }
   }
@@ -465,11 +475,11 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-      delete h;
+      conv_release(h);
       return fail(DFX_ERR_HIP, "conv_create: cannot query the device");
     }
     if (mfma_dispatch(h, nullptr, 1) != 0) {
-      delete h;
+      conv_release(h);
       return fail(DFX_ERR_HIP, "conv_create: cannot raise dynamic LDS limit to %d bytes", h->lds);
     }
     int per_cu = mfma_dispatch(h, nullptr, 2);
@@ -479,7 +489,7 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
 #ifdef DFX_STAMPS
     if (hipMalloc((void **)&h->d_prof, (size_t)h->grid * 96 * 8) != hipSuccess ||
         hipMemset(h->d_prof, 0, (size_t)h->grid * 96 * 8) != hipSuccess) {
-      delete h;
+      conv_release(h);
       return fail(DFX_ERR_HIP, "conv_create: cannot allocate the stamp buffer");
     }
     h->sgeom.prof = h->d_prof;
@@ -498,7 +508,7 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
       int dev = 0;
       hipDeviceProp_t prop;
       if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-        delete h;
+        conv_release(h);
         return fail(DFX_ERR_HIP, "conv_create: cannot query the device");
       }
       h->grid = prop.multiProcessorCount;  // one persistent workgroup (two teams) per CU
@@ -508,7 +518,7 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     h->block = MFMA_THREADS;
     if (hipMalloc((void **)&h->d_queue, 16) != hipSuccess ||
         hipMemset(h->d_queue, 0, 16) != hipSuccess) {
-      delete h;
+      conv_release(h);
       return fail(DFX_ERR_HIP, "conv_create: cannot allocate the unit queue");
     }
     h->geom.queue = h->d_queue;
@@ -521,7 +531,7 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
 #ifdef DFX_STAMPS
     if (hipMalloc((void **)&h->d_prof, (size_t)h->grid * 256 * 8) != hipSuccess ||
         hipMemset(h->d_prof, 0, (size_t)h->grid * 256 * 8) != hipSuccess) {
-      delete h;
+      conv_release(h);
       return fail(DFX_ERR_HIP, "conv_create: cannot allocate the stamp buffer");
     }
     h->geom.prof = h->d_prof;
@@ -531,7 +541,7 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_mfma_fused_kernel<%d,%d,%d,%d%s>", h->icb,
              h->ocb, h->G, d.dst_dt, fused ? "" : ",unfused");
     if (mfma_dispatch(h, nullptr, 1) != 0) {
-      delete h;
+      conv_release(h);
       return fail(DFX_ERR_HIP, "conv_create: cannot raise dynamic LDS limit to %d bytes", h->lds);
     }
   } else {
@@ -867,11 +877,7 @@ int dfx_debug_read_stamps(dfx_conv_t *h, unsigned long long *out, int max_entrie
 #endif
 
 int dfx_conv_destroy(dfx_conv_t *h) {
-  if (!h) return DFX_OK;
-  if (h->host_stream) (void)hipStreamDestroy(h->host_stream);
-  (void)hipFree(h->d_wei); (void)hipFree(h->d_wei1); (void)hipFree(h->d_consts);
-  (void)hipFree(h->d_src); (void)hipFree(h->d_dst); (void)hipFree(h->d_queue);
-  delete h;
+  conv_release(h);
   return DFX_OK;
 }
 
