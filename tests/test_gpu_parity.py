@@ -150,6 +150,46 @@ def test_stream_variant_full_size(hip, oracle, case):
     hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), info.kernel_name.decode())
 
 
+def _random_cases(n, seed, big=False):
+    """seeded random shapes inside what the reference's init_conf admits: channels multiples
+    of 16, any kernel / stride / padding with a non-empty output"""
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        kh, kw = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+        sh, sw = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        ph, pw = int(rng.integers(0, kh)), int(rng.integers(0, kw))
+        ih, iw = (int(rng.integers(1, 13)), int(rng.integers(1, 13))) if big else \
+                 (int(rng.integers(1, 24)), int(rng.integers(1, 40)))
+        if ih + 2 * ph < kh or iw + 2 * pw < kw:
+            continue
+        fused = bool(rng.integers(0, 4))
+        cmax = (21, 33, 41) if big else (9, 11, 13)   # channel counts / 16 (exclusive)
+        out.append(C.ConvCase(
+            "rnd%d" % len(out), int(rng.integers(1, 41 if big else 6)), 16 * int(rng.integers(1, cmax[0])), ih, iw,
+            16 * int(rng.integers(1, cmax[1])), 16 * int(rng.integers(1, cmax[2])) if fused else 0,
+            k=(kh, kw), stride=(sh, sw), pad=(ph, pw),
+            dst_dt=int(rng.choice([C.U8, C.S8, C.S32, C.F32])),
+            bia0_dt=int(rng.choice([C.UNDEF, C.S8, C.U8, C.S32, C.F32])),
+            bia1_dt=int(rng.choice([C.UNDEF, C.S8, C.U8, C.S32, C.F32])),
+            relu0=bool(rng.integers(0, 2)), relu1=bool(rng.integers(0, 2)),
+            rm0=int(rng.integers(0, 2)), rm1=int(rng.integers(0, 2)),
+            per_channel0=bool(rng.integers(0, 2)), per_channel1=bool(rng.integers(0, 2)),
+            wide=bool(rng.integers(0, 2)), seed=1000 + len(out)))
+    return out
+
+
+def test_random_shapes_all_variants(hip, oracle):
+    """90 seeded random shapes / option sets (30 of them many-channel, many-image): the streamed-weight MFMA kernel (auto) and the
+    scalar kernel both reproduce the oracle bit for bit."""
+    for case in _random_cases(60, 2024) + _random_cases(30, 7, big=True):
+        data = C.generate(case)
+        ref = hip.oracle_conv(oracle, case, data)
+        for fv in (-1, hip.dfa.VARIANT_GENERIC):
+            got, info = hip.hip_conv(case, data, force_variant=fv)
+            hip.assert_bit_equal(got, ref, "%s %r" % (info.kernel_name.decode(), case))
+
+
 def test_auto_variant_prefers_mfma(hip):
     """shapes outside the resident-weight kernel go to the streamed MFMA kernel, not the scalar one."""
     for case in STREAM_SHAPES[:4]:
