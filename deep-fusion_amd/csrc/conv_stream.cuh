@@ -36,6 +36,10 @@
 //  * conv1 runs D1[px][oc1] over mid with G column blocks at a time and the same
 //    channel permutation / store path as conv_mfma.cuh (lane = G consecutive
 //    channels).  The unfused op uses that orientation for the first conv directly.
+//  * Few pixels, many channels (14x14, 7x7 images): the unfused kernel can hand out (unit,
+//    output chunk) work items instead of whole units (occ_par), and the host runs a fused op
+//    whose units would not fill the machine as two such launches through a u8 intermediate
+//    in global memory (it stays in L2) -- same arithmetic, see dfx_api.hip.
 //  * u8 -> s8 offset: the compensation 128 * sum(w) is added to the raw accumulator
 //    as an INTEGER (K can reach 9 * 512 here, beyond f32's exact range), then the
 //    reference's float(acc) (+bias) * scale chain runs unchanged.
@@ -66,6 +70,8 @@ struct StreamGeom {
   int mid_stride;       // bytes per slot of the intermediate (32 * ocb + 16)
   int off_tile, off_pxoff, off_mid, off_cst, off_stage;  // LDS byte offsets (weight buffers at 0)
   int fast;             // 1: the fast requant path is valid (host proof, see conv_mfma.cuh store_group)
+  int planes;           // 1: one 64-channel input chunk in LDS at a time; n_icc: all chunks resident (staged once per item)
+  int occ_par;          // unfused only: 1 = a work item is (unit, output chunk) instead of a whole unit
 #ifdef DFX_STAMPS
   unsigned long long *prof;  // diagnostic build only: [workgroup][wave][16] cycle sums
 #endif
@@ -88,7 +94,9 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
   constexpr int GA = 2 * OCC * 64, GB = 2 * G * 64;      // 16-byte granules per conv0 / conv1 step
   constexpr int NLD = (2 * WB * 64 + ST_THREADS - 1) / ST_THREADS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char *tile = smem + g.off_tile;
+  unsigned char *const tile0 = smem + g.off_tile;
+  unsigned char *tile = tile0;  // the chunk the current phase reads
+  const int plane_bytes = g.npos * ST_POS;
   unsigned *pxoff = reinterpret_cast<unsigned *>(smem + g.off_pxoff);  // dst byte offset of each slot's pixel
   unsigned char *mid = smem + g.off_mid;
   float *cst0 = reinterpret_cast<float *>(smem + g.off_cst);  // FUSED: comp0 | bias0 | scale0 in LDS
@@ -109,21 +117,32 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
 
   // ---- weight stream: step t of a unit sits at granule woff(t) of the packed buffer ----
   v4i wreg[NLD];
+  int wmsk = 0;  // granule mask of the step held in wreg
+  const bool OCC_PAR = !FUSED && g.occ_par != 0;
+  const int n_items = OCC_PAR ? g.total_units * g.n_occ : g.total_units;
+  const int SC = OCC_PAR ? S0 / g.n_occ : S;  // steps per work item
+  int f_tl = 0, f_item = blockIdx.x, f_base = OCC_PAR ? ((int)blockIdx.x % g.n_occ) * SC : 0;
 // (No branch around a load or an LDS write: hipcc would wait vmcnt(0) inside each one.
 // A step holds a power-of-two number of granules; surplus threads repeat a granule.)
-#define DFX_W_ISSUE(T)                                                                  \
+// fetches the next step of this workgroup's step sequence into wreg and advances the
+// sequence: the steps of a work item in order, then those of the item gridDim.x further on
+#define DFX_W_FETCH()                                                                   \
   do {                                                                                  \
-    const int t_ = (T);                                                                 \
+    const int t_ = f_base + f_tl;                                                       \
     const int off_ = t_ < S0 ? t_ * GA : S0 * GA + (t_ - S0) * GB;                      \
-    const int msk_ = (t_ < S0 ? GA : GB) - 1;                                           \
+    wmsk = (t_ < S0 ? GA : GB) - 1;                                                     \
     _Pragma("unroll") for (int i = 0; i < NLD; ++i)                                     \
-      if (DFX_EXP != 1) wreg[i] = wsrc[off_ + ((tid + ST_THREADS * i) & msk_)];         \
+      if (DFX_EXP != 1) wreg[i] = wsrc[off_ + ((tid + ST_THREADS * i) & wmsk)];         \
+    if (++f_tl == SC) {                                                                 \
+      f_tl = 0;                                                                         \
+      f_item += (int)gridDim.x;                                                         \
+      f_base = (OCC_PAR && f_item < n_items) ? (f_item % g.n_occ) * SC : 0;             \
+    }                                                                                   \
   } while (0)
-#define DFX_W_COMMIT(T, BUF)                                                            \
+#define DFX_W_COMMIT(BUF)                                                               \
   do {                                                                                  \
-    const int msk_ = ((T) < S0 ? GA : GB) - 1;                                          \
     v4i *d_ = reinterpret_cast<v4i *>(smem + (BUF) * WBUF);                             \
-    _Pragma("unroll") for (int i = 0; i < NLD; ++i) d_[(tid + ST_THREADS * i) & msk_] = wreg[i]; \
+    _Pragma("unroll") for (int i = 0; i < NLD; ++i) d_[(tid + ST_THREADS * i) & wmsk] = wreg[i]; \
   } while (0)
 
   // ---- tile staging: granule q = tid + 256 i covers LDS position q >> 2, 16-byte
@@ -195,22 +214,19 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
   // Weight pipeline invariant at the start of step t: LDS buffers cur and cur+1 (mod 3)
   // hold steps t and t+1 (visible), wreg holds (in flight) step t+2.
   int cur = 0;
-  DFX_W_ISSUE(0);
-  DFX_W_COMMIT(0, 0);
-  DFX_W_ISSUE(1 % S);
-  DFX_W_COMMIT(1 % S, 1);
-  DFX_W_ISSUE(2 % S);
-  int tc = 2 % S, ti = 3 % S;  // the step wreg holds, the step to fetch next
+  DFX_W_FETCH();
+  DFX_W_COMMIT(0);
+  DFX_W_FETCH();
+  DFX_W_COMMIT(1);
+  DFX_W_FETCH();
   if (FUSED)
     for (int q = tid; q < 3 * OCP; q += ST_THREADS) cst0[q] = a.consts[q];  // visible after the first staging barrier
   bool tv_ready = false;  // tv holds the tile the next staging point needs
 #define DFX_STEP_WEIGHTS()                                                              \
   {                                                                                     \
     int b2_ = cur + 2; if (b2_ >= 3) b2_ -= 3;                                          \
-    DFX_W_COMMIT(tc, b2_);                                                              \
-    DFX_W_ISSUE(ti);                                                                    \
-    if (++tc == S) tc = 0;                                                              \
-    if (++ti == S) ti = 0;                                                              \
+    DFX_W_COMMIT(b2_);                                                                  \
+    DFX_W_FETCH();                                                                      \
   }
 #define DFX_STEP_END()                 \
   if (DFX_EXP != 5) __syncthreads();   \
@@ -262,12 +278,15 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
     if (DFX_EXP != 3) acc1[pb][cc] = mfma_i8(fb[SET][pb], fw[SET][cc], acc1[pb][cc]);   \
   }
 
-  for (int unit = blockIdx.x; unit < g.total_units; unit += gridDim.x) {
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
     DFX_STAMP(u0);
+    const int unit = OCC_PAR ? item / g.n_occ : item;
+    const int occ_lo = OCC_PAR ? item - unit * g.n_occ : 0, occ_hi = OCC_PAR ? occ_lo + 1 : g.n_occ;
+    const int next_unit = OCC_PAR ? (item + (int)gridDim.x) / g.n_occ : item + (int)gridDim.x;
     const UnitGeo ug = unit_geo(unit);
     const int thc = min(g.thv, a.oh - ug.y0), twc = min(g.twv, a.ow - ug.x0);
     const int npx = ug.nimg * thc * twc;
-    const bool has_next = unit + (int)gridDim.x < g.total_units;
+    const bool has_next = item + (int)gridDim.x < n_items;
     const bool full = npx == ST_M * PXB;  // every slot holds a pixel: the stores need no predicate
     // this lane's pixel slots (conv0 column / conv1 row), one per pixel block
     int fbase[PXB];  // the slot's input position (tap 0) in the halo tile
@@ -285,7 +304,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
       my_mid[pb] = mid + slot * g.mid_stride + h * 16;
     }
 
-    for (int occ = 0; occ < g.n_occ; ++occ) {
+    for (int occ = occ_lo; occ < occ_hi; ++occ) {
       v16i acc[PXB][OCC];
 #pragma unroll
       for (int pb = 0; pb < PXB; ++pb)
@@ -307,7 +326,29 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
         // ---- stage input chunk icc of the halo tile (all waves are past the last
         //      step that read the previous contents: every step ends in a barrier).
         //      A single-chunk input stays in LDS for all output chunks of the unit. ----
-        if (g.n_icc > 1 || occ == 0) {
+        if (g.planes > 1) {
+          // ---- all input chunks resident: stage them once per work item ----
+          if (occ == occ_lo && icc == 0) {
+            DFX_STAMP(s0);
+            if (FUSED && ESZ == 1 && G == 4) __syncthreads();  // (staging area aliases the tile, see below)
+            for (int q = tid; q < tile_q * g.planes; q += ST_THREADS) {
+              const int pl = q / tile_q, ql = q - pl * tile_q;
+              const int pos = ql >> 2, j = ql & 3;
+              const int img = pos / lhw, r = pos - img * lhw;
+              const int ly = r / g.lw, lx = r - ly * g.lw;
+              const int iy = ug.iy0 + ly, ix = ug.ix0 + lx;
+              const bool ok = img < ug.nimg && iy >= 0 && iy < a.ih && ix >= 0 && ix < a.iw && 64 * pl + 16 * j < a.ic;
+              const long long o = ok ? ug.org + (long long)((img * a.ih + ly) * a.iw + lx) * a.ic + 16 * j + 64 * pl : 0ll;
+              const v4i v = *reinterpret_cast<const v4i *>(a.src + o);
+              *reinterpret_cast<v4i *>(tile0 + pl * plane_bytes + pos * ST_POS + 16 * (j ^ chunk_swizzle<4>(pos))) =
+                  ok ? v ^ x80 : x80;
+            }
+            __syncthreads();
+            DFX_STAMP(s1);
+            DFX_ACC(0, s1 - s0);
+          }
+          tile = tile0 + icc * plane_bytes;
+        } else if (g.n_icc > 1 || occ == occ_lo) {
           DFX_STAMP(s0);
           // the 1-byte store staging area aliases the tile: every wave must be out of the
           // previous unit's epilogue before the new tile lands
@@ -363,11 +404,13 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
           DFX_STEP_WEIGHTS();
           DFX_STAMP(x6);
           if (s2 == ns2 - 1) {  // last step before the next staging point: fetch its tile now
-            if (g.n_icc > 1 && (icc + 1 < g.n_icc || occ + 1 < g.n_occ)) {
+            if (g.planes > 1) {
+              // resident chunks: nothing to prefetch here
+            } else if (g.n_icc > 1 && (icc + 1 < g.n_icc || occ + 1 < occ_hi)) {
               DFX_T_ISSUE(ug.org, ug.iy0, ug.ix0, ug.nimg, icc + 1 < g.n_icc ? icc + 1 : 0);
               tv_ready = true;
-            } else if (!FUSED && occ + 1 == g.n_occ && has_next) {
-              const UnitGeo nx = unit_geo(unit + gridDim.x);
+            } else if (!FUSED && occ + 1 == occ_hi && has_next) {
+              const UnitGeo nx = unit_geo(next_unit);
               DFX_T_ISSUE(nx.org, nx.iy0, nx.ix0, nx.nimg, 0);
               tv_ready = true;
             }
@@ -498,8 +541,8 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
             DFX_LOAD1(0, nb_, 0);
           }
           DFX_STEP_WEIGHTS();
-          if (g1 + 1 == g.n_g1 && s2 + 1 == g.ks2 && has_next) {  // next unit's first tile
-            const UnitGeo nx = unit_geo(unit + gridDim.x);
+          if (g.planes == 1 && g1 + 1 == g.n_g1 && s2 + 1 == g.ks2 && has_next) {  // next unit's first tile
+            const UnitGeo nx = unit_geo(next_unit);
             DFX_T_ISSUE(nx.org, nx.iy0, nx.ix0, nx.nimg, 0);
             tv_ready = true;
           }
@@ -582,7 +625,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
     }
   }
 #endif
-#undef DFX_W_ISSUE
+#undef DFX_W_FETCH
 #undef DFX_W_COMMIT
 #undef DFX_T_ISSUE
 #undef DFX_T_COMMIT

@@ -81,6 +81,10 @@ struct dfx_conv {
   MfmaGeom geom;
   StreamGeom sgeom;  // DFX_VARIANT_MFMA_STREAM
   int occ, pxb;      // stream variant: conv0 output blocks per chunk, pixel blocks per wave
+  // stream variant, fused op with too few units to fill the machine: run as two unfused
+  // launches (3x3 -> u8 intermediate in global memory -> 1x1), each with (unit, chunk) items
+  dfx_conv *split0, *split1;
+  void *d_mid;
   int icb, ocb, G, grid, block, lds;
   void *d_wei, *d_wei1, *d_consts;
   int *d_queue;  // MFMA variant: {next unit, finished workgroups}
@@ -308,7 +312,9 @@ static int pick_blocking(int nblocks) {
   return 1;
 }
 
-static bool pick_stream_geometry(const dfx_conv_desc &d, int OCC, int G, int PXB, StreamGeom &g, int &lds) {
+// chunk_par: the op will hand out (unit, output chunk) items (one output chunk per item)
+static bool pick_stream_geometry(const dfx_conv_desc &d, int OCC, int G, int PXB, bool chunk_par, StreamGeom &g,
+                                 int &lds) {
   const int M = ST_M * PXB;  // pixel slots per unit
   const bool fused = d.oc1x1 > 0;
   const int icb = (d.ic + 31) / 32, ocb_real = (d.oc + 31) / 32;
@@ -357,8 +363,20 @@ static bool pick_stream_geometry(const dfx_conv_desc &d, int OCC, int G, int PXB
   g.ux = (d.ow + g.twv - 1) / g.twv;
   g.total_units = (d.bs + g.ni - 1) / g.ni * g.uy * g.ux;
   g.off_tile = 3 * 2 * WB * 1024;  // three weight buffers
+  // All input chunks resident in LDS (staged once per work item, without register prefetch)
+  // instead of one chunk at a time (prefetched): pays when a work item would otherwise stage
+  // every chunk once per output chunk, or when a chunk has too few steps to hide the next
+  // fetch (1x1 kernels) -- if that still leaves room for two workgroups per CU.
+  g.planes = 1;
+  const bool restaged = !chunk_par && g.n_occ > 1;
+  const bool short_chunks = d.kh * d.kw <= 2;
+  if (g.n_icc > 1 && (restaged || short_chunks) &&
+      fixed + std::max((size_t)g.n_icc * g.npos * ST_POS + 16, stage_bytes) <= 81920)
+    g.planes = g.n_icc;
+  if (const char *e = getenv("DFX_STREAM_PLANES"))  // testing aid: 0 = never, 1 = whenever it fits LDS at all
+    g.planes = (atoi(e) && g.n_icc > 1 && fixed + std::max((size_t)g.n_icc * g.npos * ST_POS + 16, stage_bytes) <= lds_max) ? g.n_icc : 1;
   // +16: the staging dump slot; the 1-byte store staging areas alias the tile
-  g.off_pxoff = (int)round16((size_t)g.off_tile + std::max((size_t)g.npos * ST_POS + 16, stage_bytes));
+  g.off_pxoff = (int)round16((size_t)g.off_tile + std::max((size_t)g.planes * g.npos * ST_POS + 16, stage_bytes));
   g.off_mid = g.off_pxoff + 4 * M;
   g.off_cst = g.off_mid + (fused ? M * g.mid_stride : 0);
   g.off_stage = g.off_tile;
@@ -404,6 +422,9 @@ static void conv_release(dfx_conv *h) {
   (void)hipFree(h->d_wei); (void)hipFree(h->d_wei1); (void)hipFree(h->d_consts);
   (void)hipFree(h->d_src); (void)hipFree(h->d_dst); (void)hipFree(h->d_queue);
   (void)hipFree(h->d_prof);
+  (void)hipFree(h->d_mid);
+  conv_release(h->split0);
+  conv_release(h->split1);
   delete h;
 }
 
@@ -458,11 +479,11 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     }
     h->pxb = 2;
     if (const char *e = getenv("DFX_STREAM_PXB")) h->pxb = atoi(e) == 1 ? 1 : 2;  // tuning aid
-    stream_ok = h->pxb == 2 && pick_stream_geometry(d, h->occ, h->G, 2, h->sgeom, h->lds) &&
+    stream_ok = h->pxb == 2 && pick_stream_geometry(d, h->occ, h->G, 2, false, h->sgeom, h->lds) &&
                 ((h->sgeom.total_units >= 4 * ncu && h->lds <= 81920) || getenv("DFX_STREAM_PXB"));
     if (!stream_ok) {
       h->pxb = 1;
-      stream_ok = pick_stream_geometry(d, h->occ, h->G, 1, h->sgeom, h->lds);
+      stream_ok = pick_stream_geometry(d, h->occ, h->G, 1, false, h->sgeom, h->lds);
     }
     if (!stream_ok && d.force_variant == DFX_VARIANT_MFMA_STREAM) {
       conv_release(h);
@@ -484,7 +505,41 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     }
     int per_cu = mfma_dispatch(h, nullptr, 2);
     if (per_cu < 1) per_cu = 1;
-    h->grid = std::min(h->sgeom.total_units, prop.multiProcessorCount * per_cu);
+    const int capacity = prop.multiProcessorCount * per_cu;  // resident workgroups
+    // unfused op whose units leave workgroup slots empty: hand out (unit, output chunk) items
+    h->sgeom.occ_par = (d.oc1x1 == 0 && h->sgeom.n_occ > 1 && h->sgeom.total_units < 2 * capacity) ? 1 : 0;
+    if (const char *e = getenv("DFX_STREAM_OCC_PAR")) h->sgeom.occ_par = (d.oc1x1 == 0 && h->sgeom.n_occ > 1 && atoi(e)) ? 1 : 0;  // testing aid
+    if (h->sgeom.occ_par) {  // lay LDS out again for one output chunk per item (same units)
+      const int units = h->sgeom.total_units;
+      if (!pick_stream_geometry(d, h->occ, h->G, h->pxb, true, h->sgeom, h->lds) || h->sgeom.total_units != units ||
+          mfma_dispatch(h, nullptr, 1) != 0) {
+        conv_release(h);
+        return fail(DFX_ERR_HIP, "conv_create: internal: chunk-parallel layout failed");
+      }
+      h->sgeom.occ_par = 1;
+    }
+    h->grid = std::min(h->sgeom.total_units * (h->sgeom.occ_par ? h->sgeom.n_occ : 1), capacity);
+    // fused op that cannot fill the machine with units: split (see struct dfx_conv)
+    // (measured: res5-style 64 units 199 -> 91 us; res4-style 196 units 64 -> 96 us, so only
+    // below a quarter of the machine)
+    bool split = d.oc1x1 > 0 && 4 * h->sgeom.total_units <= capacity &&
+                 ((d.oc + 127) / 128 > 1 || (d.oc1x1 + 127) / 128 > 1);
+    if (const char *e = getenv("DFX_STREAM_SPLIT")) split = d.oc1x1 > 0 && atoi(e) != 0;  // testing aid
+    if (split) {
+      dfx_conv_desc d0 = d, d1 = d;
+      d0.oc1x1 = 0; d0.dst_dt = DFX_U8; d0.bia1_dt = DFX_UNDEF; d0.conv1_nscales = 1;
+      d0.force_variant = DFX_VARIANT_MFMA_STREAM;
+      d1.ic = d.oc; d1.ih = d.oh; d1.iw = d.ow; d1.oc = d.oc1x1; d1.kh = d1.kw = 1; d1.sh = d1.sw = 1;
+      d1.pad_t = d1.pad_l = 0; d1.oc1x1 = 0; d1.bia0_dt = d.bia1_dt; d1.bia1_dt = DFX_UNDEF;
+      d1.conv0_relu = d.conv1_relu; d1.conv0_round_mode = d.conv1_round_mode; d1.conv0_nscales = d.conv1_nscales;
+      d1.conv1_nscales = 1; d1.force_variant = DFX_VARIANT_MFMA_STREAM;
+      if (dfx_conv_create(&d0, &h->split0) != DFX_OK || dfx_conv_create(&d1, &h->split1) != DFX_OK ||
+          hipMalloc(&h->d_mid, (size_t)d.bs * d.oh * d.ow * d.oc) != hipSuccess) {
+        conv_release(h->split0); conv_release(h->split1);
+        (void)hipFree(h->d_mid);
+        h->split0 = h->split1 = nullptr; h->d_mid = nullptr;  // fall back to the single fused launch
+      }
+    }
     if (const char *e = getenv("DFX_STREAM_GRID")) h->grid = std::max(1, std::min(h->grid, atoi(e)));  // testing aid
 #ifdef DFX_STAMPS
     if (hipMalloc((void **)&h->d_prof, (size_t)h->grid * 96 * 8) != hipSuccess ||
@@ -496,8 +551,12 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
 #endif
     a.rows_per_unit = h->sgeom.thv;
     a.units_per_image = h->sgeom.uy * h->sgeom.ux;
-    snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_stream_kernel<%d,%d,%d,%d,%s>", h->occ, h->G, h->pxb,
-             d.dst_dt, d.oc1x1 ? "fused" : "unfused");
+    if (h->split0)
+      snprintf(h->kernel_name, sizeof(h->kernel_name), "split: conv_stream<%d,%d,u8> %d items + conv_stream<%d,%d,%d> %d items",
+               h->split0->occ, h->split0->pxb, h->split0->grid, h->split1->occ, h->split1->pxb, d.dst_dt, h->split1->grid);
+    else
+      snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_stream_kernel<%d,%d,%d,%d,%s%s>", h->occ, h->G, h->pxb,
+               d.dst_dt, d.oc1x1 ? "fused" : "unfused", h->sgeom.occ_par ? ",occ_par" : "");
   } else if (want_mfma && pick_geometry(d, h->geom, h->lds)) {
     const bool fused = d.oc1x1 > 0;
     h->variant = fused ? DFX_VARIANT_MFMA_FUSED : DFX_VARIANT_MFMA_CONV;
@@ -702,6 +761,12 @@ int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei, const void *bia0, con
     s1[c] = scales1[d.conv1_nscales > 1 ? c : 0];
   }
 
+  if (h->split0) {  // the two halves of a split fused op take their own weights
+    int rc = dfx_conv_set_weights(h->split0, wei, bia0, scales0, nullptr, nullptr, nullptr);
+    if (rc == DFX_OK) rc = dfx_conv_set_weights(h->split1, wei1, bia1, scales1, nullptr, nullptr, nullptr);
+    h->weights_set = rc == DFX_OK;
+    return rc;
+  }
   if (h->variant == DFX_VARIANT_MFMA_STREAM) return set_weights_stream(h, wei, bia0, scales0, wei1, bia1, scales1);
 
   if (h->variant != DFX_VARIANT_GENERIC) {
@@ -816,6 +881,10 @@ int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei, const void *bia0, con
 int dfx_conv_submit(dfx_conv_t *h, const void *src_dev, void *dst_dev, dfx_stream_t s) {
   if (!h || !src_dev || !dst_dev) return fail(DFX_ERR_INVALID, "conv_submit: null argument");
   if (!h->weights_set) return fail(DFX_ERR_STATE, "conv_submit: dfx_conv_set_weights not called");
+  if (h->split0) {
+    int rc0 = dfx_conv_submit(h->split0, src_dev, h->d_mid, s);
+    return rc0 != DFX_OK ? rc0 : dfx_conv_submit(h->split1, h->d_mid, dst_dev, s);
+  }
   h->args.src = (const uint8_t *)src_dev;
   h->args.dst = dst_dev;
   int rc;

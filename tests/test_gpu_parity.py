@@ -150,6 +150,43 @@ def test_stream_variant_full_size(hip, oracle, case):
     hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), info.kernel_name.decode())
 
 
+@pytest.mark.parametrize("planes", ["0", "1"])
+def test_stream_variant_resident_input_chunks(hip, oracle, monkeypatch, planes):
+    """DFX_STREAM_PLANES: all 64-channel input chunks resident in LDS (staged once per work
+    item) vs one chunk at a time, on inputs with several chunks."""
+    monkeypatch.setenv("DFX_STREAM_PLANES", planes)
+    cases = [c for c in STREAM_SHAPES if c.ic > 64] + [
+        C.ConvCase("ic192", 3, 192, 9, 12, 160, 144, dst_dt=C.U8, wide=True),
+        C.ConvCase("ic320", 2, 320, 5, 6, 272, 0, dst_dt=C.S32, k=(1, 1), pad=(0, 0)),
+        C.ConvCase("ic144s2", 2, 144, 11, 9, 64, 256, stride=(2, 2), dst_dt=C.S8, relu1=False)]
+    for grid in ("", "2"):
+        if grid:
+            monkeypatch.setenv("DFX_STREAM_GRID", grid)
+        for case in cases:
+            data = C.generate(case)
+            got, info = hip.hip_conv(case, data, force_variant=hip.dfa.VARIANT_MFMA_STREAM)
+            hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), info.kernel_name.decode() + " " + case.ident())
+
+
+@pytest.mark.parametrize("mode", ["DFX_STREAM_OCC_PAR", "DFX_STREAM_SPLIT"])
+def test_stream_variant_chunk_parallel_and_split(hip, oracle, monkeypatch, mode):
+    """(unit, output chunk) work items for unfused ops, and fused ops run as two such
+    launches through a u8 intermediate: forced on shapes that would not pick them."""
+    monkeypatch.setenv(mode, "1")
+    cases = STREAM_SHAPES + C.dtype_matrix(C.SMALL) + [C.CONFIG3_SMALL, replace(C.CONFIG3_SMALL, dst_dt=C.U8, wide=True)]
+    if mode == "DFX_STREAM_OCC_PAR":
+        cases = [C.unfused(c) if c.oc1x1 else c for c in cases] + [
+            C.ConvCase("oc512", 3, 64, 7, 7, 512, 0, dst_dt=C.S8, relu0=False),
+            C.ConvCase("oc320s2", 2, 48, 9, 11, 320, 0, stride=(2, 2), dst_dt=C.F32)]
+    for grid in ("", "2"):
+        if grid:
+            monkeypatch.setenv("DFX_STREAM_GRID", grid)
+        for case in cases:
+            data = C.generate(case)
+            got, info = hip.hip_conv(case, data, force_variant=hip.dfa.VARIANT_MFMA_STREAM)
+            hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), info.kernel_name.decode() + " " + case.ident())
+
+
 def _random_cases(n, seed, big=False):
     """seeded random shapes inside what the reference's init_conf admits: channels multiples
     of 16, any kernel / stride / padding with a non-empty output"""
