@@ -86,12 +86,30 @@ def cpu_baseline(case, data, threads, gpu_out, budget_s=12.0):
         el = time.perf_counter() - t0
         if el > budget_s or reps >= 100:
             break
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "unknown")
+    except OSError:
+        pass
     return {"value": round(n * reps / el, 2), "unit": "images/sec", "cores": orc.num_threads(),
+            "cpu_model": cpu_model, "host_cpus": os.cpu_count(),
             "kind": "port", "gpu_output_matches_oracle": True,
             "sample": "%d images x %d reps of the same workload, oracle impl=%s (%s)" % (
                 n, reps, impl,
                 "AVX-512 VNNI intrinsics mirroring the reference JIT, OpenMP over (n,oh)"
                 if impl == "avx512" else "scalar C, OpenMP over (n,oh)")}
+
+
+def calibrated_peak(hbm_bound):
+    """measured roofs of the gpurun MI355X (write stream in the kernel's store shape; back-to-back
+    int8 MFMA), see profiles/calibration.json; None if the file is missing"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "calibration.json")) as f:
+            c = json.load(f)
+        return float(c["hbm_write_GBps"] if hbm_bound else c["int8_mfma_TOPs"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def load_traffic(workload, dst):
@@ -214,6 +232,10 @@ def main():
                          "unit": "GB/s" if hbm_bound else "TOP/s",
                          "frac": round((achieved / HBM_PEAK_GBS) if hbm_bound else (tops / INT8_PEAK_TOPS), 4),
                          "traffic": load_traffic(args.workload, dst_name),
+                         # nominal AND calibrated denominators (profiles/calibration.json)
+                         "peak_calibrated": calibrated_peak(hbm_bound),
+                         "frac_of_calibrated": round((achieved if hbm_bound else tops) / calibrated_peak(hbm_bound), 4)
+                         if calibrated_peak(hbm_bound) else None,
                          "kernel_ms": round(kern_ms, 5),
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "algorithmic_ops_per_launch": alg_ops,
