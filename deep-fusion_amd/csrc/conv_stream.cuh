@@ -164,20 +164,22 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
   // ---- input tile prefetch registers (first ST_TQ granules per thread) ----
   v4i tv[ST_TQ];
   int tv_ok = 0;  // bit i: tv[i] is a real pixel granule (else padding)
-#define DFX_T_ISSUE(ORG, IY0, IX0, NIMG, ICC)                                           \
+#define DFX_T_ISSUE(N0, IY0, IX0, NIMG, ICC)                                            \
   do {                                                                                  \
     const int cb0_ = 64 * (ICC);                                                        \
     _Pragma("unroll") for (int i = 0; i < ST_TQ; ++i) {                                 \
       const int q_ = tid + ST_THREADS * i;                                              \
       const int img_ = tq_pos[i] >> 20, ly_ = (tq_pos[i] >> 10) & 1023, lx_ = tq_pos[i] & 1023; \
-      const int iy_ = (IY0) + ly_, ix_ = (IX0) + lx_;                                   \
+      const int iy_ = (IY0) + ly_, ix_ = (IX0) + lx_, cb_ = cb0_ + 16 * (q_ & 3);       \
       const bool ok_ = q_ < tile_q && img_ < (NIMG) && iy_ >= 0 && iy_ < a.ih && ix_ >= 0 && \
-                       ix_ < a.iw && cb0_ + 16 * (q_ & 3) < a.ic;                       \
-      const int rel_ = ((img_ * a.ih + ly_) * a.iw + lx_) * a.ic + 16 * (q_ & 3);      \
-      /* branch-free: granules outside the image read src[0..15] and are zeroed */      \
-      const long long o_ = ok_ ? (ORG) + rel_ + cb0_ : 0ll;                             \
+                       ix_ < a.iw && cb_ < a.ic;                                        \
+      /* always an in-range address (clamped coordinates); padding is zeroed at commit: \
+         no branch and no select around the load */                                     \
+      const int n_ = min((N0) + img_, a.bs - 1), y_ = min(max(iy_, 0), a.ih - 1);       \
+      const int x_ = min(max(ix_, 0), a.iw - 1), c_ = min(cb_, a.ic - 16);              \
+      const long long o_ = (((long long)n_ * a.ih + y_) * a.iw + x_) * a.ic + c_;       \
       if (DFX_EXP != 6) tv[i] = *reinterpret_cast<const v4i *>(a.src + o_);             \
-      tv_ok = ok_ ? (tv_ok | (1 << i)) : (tv_ok & ~(1 << i)); /* zeroed at commit: no wait here */ \
+      tv_ok = ok_ ? (tv_ok | (1 << i)) : (tv_ok & ~(1 << i));                           \
     }                                                                                   \
   } while (0)
 /* granules beyond the tile go to a 16-byte dump slot right behind it */                  
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
   } while (0)
 
   const int upg = g.uy * g.ux;
-  struct UnitGeo { int n0, y0, x0, nimg, iy0, ix0; long long org; };
+  struct UnitGeo { int n0, y0, x0, nimg, iy0, ix0; };
   auto unit_geo = [&](int unit) {
     UnitGeo r;
     const int grp = unit / upg, u = unit - grp * upg;
@@ -199,8 +201,6 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
     r.n0 = grp * g.ni; r.y0 = uyi * g.thv; r.x0 = uxi * g.twv;
     r.nimg = min(g.ni, a.bs - r.n0);
     r.iy0 = r.y0 * a.sh - a.pt; r.ix0 = r.x0 * a.sw - a.pl;
-    // origin of the halo tile in src (may point before the image: only used with valid offsets)
-    r.org = (((long long)r.n0 * a.ih + r.iy0) * a.iw + r.ix0) * a.ic;
     return r;
   };
   const bool fast = g.fast != 0;
@@ -338,7 +338,8 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
               const int ly = r / g.lw, lx = r - ly * g.lw;
               const int iy = ug.iy0 + ly, ix = ug.ix0 + lx;
               const bool ok = img < ug.nimg && iy >= 0 && iy < a.ih && ix >= 0 && ix < a.iw && 64 * pl + 16 * j < a.ic;
-              const long long o = ok ? ug.org + (long long)((img * a.ih + ly) * a.iw + lx) * a.ic + 16 * j + 64 * pl : 0ll;
+              const int n_ = min(ug.n0 + img, a.bs - 1), y_ = min(max(iy, 0), a.ih - 1), x_ = min(max(ix, 0), a.iw - 1);
+              const long long o = (((long long)n_ * a.ih + y_) * a.iw + x_) * a.ic + min(64 * pl + 16 * j, a.ic - 16);
               const v4i v = *reinterpret_cast<const v4i *>(a.src + o);
               *reinterpret_cast<v4i *>(tile0 + pl * plane_bytes + pos * ST_POS + 16 * (j ^ chunk_swizzle<4>(pos))) =
                   ok ? v ^ x80 : x80;
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
           // the 1-byte store staging area aliases the tile: every wave must be out of the
           // previous unit's epilogue before the new tile lands
           if (FUSED && ESZ == 1 && G == 4 && occ == 0 && icc == 0) __syncthreads();
-          if (!tv_ready) DFX_T_ISSUE(ug.org, ug.iy0, ug.ix0, ug.nimg, icc);
+          if (!tv_ready) DFX_T_ISSUE(ug.n0, ug.iy0, ug.ix0, ug.nimg, icc);
           DFX_T_COMMIT();
           tv_ready = false;
           const int cb0 = 64 * icc;
@@ -363,11 +364,10 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
             const int ly = r / g.lw, lx = r - ly * g.lw;
             const int iy = ug.iy0 + ly, ix = ug.ix0 + lx;
             const bool ok = img < ug.nimg && iy >= 0 && iy < a.ih && ix >= 0 && ix < a.iw && cb0 + 16 * j < a.ic;
-            v4i v = v4i{0, 0, 0, 0};
-            if (ok)
-              v = *reinterpret_cast<const v4i *>(
-                  a.src + (ug.org + (long long)((img * a.ih + ly) * a.iw + lx) * a.ic + 16 * j + cb0));
-            *reinterpret_cast<v4i *>(tile + pos * ST_POS + 16 * (j ^ chunk_swizzle<4>(pos))) = v ^ x80;
+            const int n_ = min(ug.n0 + img, a.bs - 1), y_ = min(max(iy, 0), a.ih - 1), x_ = min(max(ix, 0), a.iw - 1);
+            const long long o = (((long long)n_ * a.ih + y_) * a.iw + x_) * a.ic + min(cb0 + 16 * j, a.ic - 16);
+            const v4i v = *reinterpret_cast<const v4i *>(a.src + o);
+            *reinterpret_cast<v4i *>(tile + pos * ST_POS + 16 * (j ^ chunk_swizzle<4>(pos))) = ok ? v ^ x80 : x80;
           }
           __syncthreads();
           DFX_STAMP(s1);
@@ -407,11 +407,11 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
             if (g.planes > 1) {
               // resident chunks: nothing to prefetch here
             } else if (g.n_icc > 1 && (icc + 1 < g.n_icc || occ + 1 < occ_hi)) {
-              DFX_T_ISSUE(ug.org, ug.iy0, ug.ix0, ug.nimg, icc + 1 < g.n_icc ? icc + 1 : 0);
+              DFX_T_ISSUE(ug.n0, ug.iy0, ug.ix0, ug.nimg, icc + 1 < g.n_icc ? icc + 1 : 0);
               tv_ready = true;
             } else if (!FUSED && occ + 1 == occ_hi && has_next) {
               const UnitGeo nx = unit_geo(next_unit);
-              DFX_T_ISSUE(nx.org, nx.iy0, nx.ix0, nx.nimg, 0);
+              DFX_T_ISSUE(nx.n0, nx.iy0, nx.ix0, nx.nimg, 0);
               tv_ready = true;
             }
           }
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
           DFX_STEP_WEIGHTS();
           if (g.planes == 1 && g1 + 1 == g.n_g1 && s2 + 1 == g.ks2 && has_next) {  // next unit's first tile
             const UnitGeo nx = unit_geo(next_unit);
-            DFX_T_ISSUE(nx.org, nx.iy0, nx.ix0, nx.nimg, 0);
+            DFX_T_ISSUE(nx.n0, nx.iy0, nx.ix0, nx.nimg, 0);
             tv_ready = true;
           }
           DFX_FENCE();

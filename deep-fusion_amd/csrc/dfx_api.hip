@@ -22,6 +22,7 @@
 
 #include "conv_mfma.cuh"
 #include "conv_stream.cuh"
+#include "conv_direct.cuh"
 #include "dfx_device.cuh"
 
 namespace dfx {
@@ -43,6 +44,14 @@ DFX_DECL(u8);
 
 #define DFX_DECL(n) \
   int launch_conv_stream_##n(const ConvArgs &, const StreamGeom &, int, int, int, int, int, int, hipStream_t, int)
+DFX_DECL(f32);
+DFX_DECL(s32);
+DFX_DECL(s8);
+DFX_DECL(u8);
+#undef DFX_DECL
+
+#define DFX_DECL(n) \
+  int launch_conv_direct_##n(const ConvArgs &, const DirectGeom &, int, int, int, int, int, hipStream_t, int)
 DFX_DECL(f32);
 DFX_DECL(s32);
 DFX_DECL(s8);
@@ -80,6 +89,8 @@ struct dfx_conv {
   ConvArgs args;
   MfmaGeom geom;
   StreamGeom sgeom;  // DFX_VARIANT_MFMA_STREAM
+  DirectGeom dgeom;  // DFX_VARIANT_MFMA_STREAM served by conv_direct.cuh (fused ops): direct != 0
+  int direct, wo, wo1;
   int occ, pxb;      // stream variant: conv0 output blocks per chunk, pixel blocks per wave
   // stream variant, fused op with too few units to fill the machine: run as two unfused
   // launches (3x3 -> u8 intermediate in global memory -> 1x1), each with (unit, chunk) items
@@ -302,6 +313,69 @@ static bool mfma_eligible(const dfx_conv_desc &d) {  // fused or unfused (oc1x1 
          (d.ic == 32 || d.ic == 64) && (d.oc == 32 || d.oc == 64) && d.oc1x1 % 32 == 0;
 }
 
+// ---- direct-weight fused kernel (conv_direct.cuh) ----
+static bool pick_direct_geometry(const dfx_conv_desc &d, int WO, int G, DirectGeom &g, int &lds) {
+  const int M = DK_M;
+  const int ocb_real = (d.oc + 31) / 32;
+  g.icb = (d.ic + 31) / 32;
+  g.n_planes = (g.icb + 1) / 2;
+  if (g.n_planes > 15) return false;  // (packed into 4 bits in the staging table)
+  g.ocb = (ocb_real + WO - 1) / WO * WO;
+  g.n_g1 = ((d.oc1x1 + 31) / 32 + G - 1) / G;
+  g.mid_stride = 32 * g.ocb + 16;
+  const size_t cst_bytes = round16((size_t)3 * 32 * g.ocb * 4);
+  const size_t stage_bytes = (G == 4 && dt_size(d.dst_dt) == 1) ? (size_t)4 * DK_STAGE : 0;
+  const size_t fixed = 4 * M + (size_t)M * g.mid_stride + cst_bytes;
+  const size_t lds_max = 163840;
+  if ((long long)d.bs * d.oh * d.ow * d.oc1x1 * (long long)dt_size(d.dst_dt) >= (1LL << 32) - 16 ||
+      (long long)d.bs * d.oh * d.ow >= (1LL << 31) || (long long)d.ih * d.iw * d.ic * M >= (1LL << 31))
+    return false;
+  double best = -1.0;
+  auto consider = [&](int ni, int thv, int twv) {
+    const int lh = (thv - 1) * d.sh + d.kh, lw = (twv - 1) * d.sw + d.kw;
+    if (lh >= 1024 || lw >= 1024 || ni >= 256) return;
+    const long long npos = (long long)ni * lh * lw;
+    const size_t tile = std::max((size_t)((long long)g.n_planes * npos * DK_POS + 16), stage_bytes);
+    if (fixed + tile > lds_max) return;
+    const double groups = (double)((d.bs + ni - 1) / ni);
+    const double units = groups * ((d.oh + thv - 1) / thv) * ((d.ow + twv - 1) / twv);
+    const double util = (double)d.bs * d.oh * d.ow / (units * M);
+    const double halo = (double)thv * d.sh * twv * d.sw / ((double)lh * lw);
+    const double two = fixed + tile <= 81920 ? 1.0 : 0.8;  // two workgroups per CU
+    const double score = util * (0.8 + 0.2 * std::min(1.0, halo)) * two;
+    if (score > best) {
+      best = score;
+      g.ni = ni; g.thv = thv; g.twv = twv; g.lh = lh; g.lw = lw; g.npos = (int)npos;
+    }
+  };
+  if (d.oh * d.ow <= M) {
+    for (int ni = std::min(d.bs, M / (d.oh * d.ow)); ni >= 1; --ni) consider(ni, d.oh, d.ow);
+  } else {
+    for (int twv = 1; twv <= std::min(d.ow, M); ++twv) consider(1, std::min(d.oh, M / twv), twv);
+  }
+  if (best < 0) return false;
+  g.uy = (d.oh + g.thv - 1) / g.thv;
+  g.ux = (d.ow + g.twv - 1) / g.twv;
+  g.total_units = (d.bs + g.ni - 1) / g.ni * g.uy * g.ux;
+  g.plane_bytes = g.npos * DK_POS;
+  g.off_pxoff = (int)round16(std::max((size_t)g.n_planes * (size_t)g.plane_bytes + 16, stage_bytes));
+  g.off_mid = g.off_pxoff + 4 * M;
+  g.off_cst = g.off_mid + M * g.mid_stride;
+  lds = g.off_cst + (int)cst_bytes;
+  g.fast = 0;
+  return true;
+}
+
+static int direct_dispatch(dfx_conv *h, hipStream_t s, int mode) {
+  switch (h->d.dst_dt) {
+    case DFX_F32: return launch_conv_direct_f32(h->args, h->dgeom, h->wo, h->G, h->wo1, h->grid, h->lds, s, mode);
+    case DFX_S32: return launch_conv_direct_s32(h->args, h->dgeom, h->wo, h->G, h->wo1, h->grid, h->lds, s, mode);
+    case DFX_S8: return launch_conv_direct_s8(h->args, h->dgeom, h->wo, h->G, h->wo1, h->grid, h->lds, s, mode);
+    case DFX_U8: return launch_conv_direct_u8(h->args, h->dgeom, h->wo, h->G, h->wo1, h->grid, h->lds, s, mode);
+  }
+  return -1;
+}
+
 // ---- streamed-weight variant (conv_stream.cuh) ----
 // blocks per chunk / group: the largest of {4,2,1} that pads the block count by <= 1/3
 static int pick_blocking(int nblocks) {
@@ -396,7 +470,7 @@ static int stream_dispatch(dfx_conv *h, hipStream_t s, int mode) {
 }
 
 static int mfma_dispatch(dfx_conv *h, hipStream_t s, int mode) {
-  if (h->variant == DFX_VARIANT_MFMA_STREAM) return stream_dispatch(h, s, mode);
+  if (h->variant == DFX_VARIANT_MFMA_STREAM) return h->direct ? direct_dispatch(h, s, mode) : stream_dispatch(h, s, mode);
   if (h->variant == DFX_VARIANT_MFMA_CONV) {
     switch (h->d.dst_dt) {
       case DFX_F32: return launch_conv_mfma_f32_unfused(h->args, h->geom, h->icb, h->ocb, h->grid, h->lds, s, mode);
@@ -490,7 +564,65 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
       return fail(DFX_ERR_UNSUPPORTED, "conv_create: shape does not fit the streamed MFMA variant");
     }
   }
-  if (stream_ok) {
+  // The direct-weight kernel (conv_direct.cuh) serves fused ops with >= 64 channels on both
+  // sides.  Measured against conv_stream.cuh (N=128, u8 out): it wins where the first
+  // contraction is deep (res4-style 256 input channels: 58 vs 65 us), ties at 128 (60 vs 58)
+  // and loses where its whole-tile staging drops LDS occupancy (stride 2) or where too few
+  // units exist and conv_stream's split execution applies -- so: ic >= 256 and enough units.
+  // DFX_STREAM_DIRECT=1/0 forces it on (wherever it fits) / off.
+  bool want_direct = stream_ok && d.oc1x1 > 0 && d.oc >= 64 && d.oc1x1 >= 64 && d.ic >= 256 &&
+                     4 * h->sgeom.total_units > 2 * 256;
+  if (const char *e = getenv("DFX_STREAM_DIRECT")) want_direct = stream_ok && d.oc1x1 > 0 && d.oc >= 64 && d.oc1x1 >= 64 && atoi(e) != 0;
+  if (want_direct) {
+    const int ocb2 = ((d.oc + 31) / 32 + 1) / 2 * 2;
+    h->wo = ocb2 % 4 == 0 ? 4 : 2;
+    const int ncb1 = (d.oc1x1 + 31) / 32;
+    const int G = ncb1 >= 3 ? 4 : 2;
+    h->wo1 = 1;
+    int lds = 0;
+    if (pick_direct_geometry(d, h->wo, G, h->dgeom, lds)) {
+      h->direct = 1;
+      h->G = G;
+      h->lds = lds;
+    }
+  }
+  if (stream_ok && h->direct) {
+    h->variant = DFX_VARIANT_MFMA_STREAM;
+    h->block = DK_THREADS;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+      conv_release(h);
+      return fail(DFX_ERR_HIP, "conv_create: cannot query the device");
+    }
+    if (mfma_dispatch(h, nullptr, 1) != 0) {
+      conv_release(h);
+      return fail(DFX_ERR_HIP, "conv_create: cannot raise dynamic LDS limit to %d bytes", h->lds);
+    }
+    int per_cu = mfma_dispatch(h, nullptr, 2);
+    if (per_cu < 1) per_cu = 1;
+    h->grid = std::min(h->dgeom.total_units, prop.multiProcessorCount * per_cu);
+    if (const char *e = getenv("DFX_STREAM_GRID")) h->grid = std::max(1, std::min(h->grid, atoi(e)));  // testing aid
+    a.rows_per_unit = h->dgeom.thv;
+    a.units_per_image = h->dgeom.uy * h->dgeom.ux;
+    snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_direct_kernel<%d,%d,%d,%d>", h->wo, h->G, h->wo1, d.dst_dt);
+#ifdef DFX_STAMPS
+    if (hipMalloc((void **)&h->d_prof, (size_t)h->grid * 64 * 8) != hipSuccess || hipMemset(h->d_prof, 0, (size_t)h->grid * 64 * 8) != hipSuccess) {
+      conv_release(h);
+      return fail(DFX_ERR_HIP, "conv_create: cannot allocate the stamp buffer");
+    }
+    h->dgeom.prof = h->d_prof;
+#endif
+#ifdef DK_DEBUG
+    if (hipMalloc((void **)&h->d_prof, 64 * 8) != hipSuccess || hipMemset(h->d_prof, 0xff, 64 * 8) != hipSuccess) {
+      conv_release(h);
+      return fail(DFX_ERR_HIP, "conv_create: cannot allocate the debug buffer");
+    }
+    h->dgeom.dbg = (long long *)h->d_prof;
+    h->dgeom.src_bytes = (long long)d.bs * d.ih * d.iw * d.ic;
+    h->dgeom.dst_bytes = (long long)d.bs * d.oh * d.ow * d.oc1x1 * (long long)dt_size(d.dst_dt);
+#endif
+  } else if (stream_ok) {
     h->variant = DFX_VARIANT_MFMA_STREAM;
     h->block = ST_THREADS;
     int dev = 0;
@@ -639,8 +771,12 @@ static bool fast_ok_channel(double amax, double comp, float bias, float scale) {
 // Packs weights for conv_stream.cuh: ONE device buffer
 //   [conv0 steps | conv1 steps | consts], a step = 2 k-blocks x (OCC | G) fragments of 1 KB,
 // in the exact order the kernel walks them (oc chunk, ic chunk, step; 1x1 group, step).
+static int set_weights_direct(dfx_conv_t *h, const int8_t *wei, const void *bia0, const float *scales0,
+                              const int8_t *wei1, const void *bia1, const float *scales1);
+
 static int set_weights_stream(dfx_conv_t *h, const int8_t *wei, const void *bia0, const float *scales0,
                               const int8_t *wei1, const void *bia1, const float *scales1) {
+  if (h->direct) return set_weights_direct(h, wei, bia0, scales0, wei1, bia1, scales1);
   const dfx_conv_desc &d = h->d;
   const StreamGeom &g = h->sgeom;
   const bool fused = d.oc1x1 > 0;
@@ -732,6 +868,92 @@ static int set_weights_stream(dfx_conv_t *h, const int8_t *wei, const void *bia0
   h->args.wei1 = (const int8_t *)(base + n0);
   h->args.consts = (const float *)(base + pk.size());
   h->weights_set = true;
+  return DFX_OK;
+}
+
+// Packs weights for conv_direct.cuh: ONE device buffer [W0d | W1d | consts].
+//   W0d[ob][kb = icb * ntap + tap][lane][16]: byte b of lane = W0[oc = 32 ob + (lane & 31)][ic = 32 icb + 16 (lane >> 5) + b][tap]
+//   W1d[g1][blk][cc][lane][16]: byte b = W1[oc1 = 32 G g1 + G (lane & 31) + cc][oc = 32 blk + 8 (b >> 2) + 4 (lane >> 5) + (b & 3)]
+static int set_weights_direct(dfx_conv_t *h, const int8_t *wei, const void *bia0, const float *scales0,
+                              const int8_t *wei1, const void *bia1, const float *scales1) {
+  const dfx_conv_desc &d = h->d;
+  const DirectGeom &g = h->dgeom;
+  const int G = h->G, OC = d.oc, IC = d.ic, OC1 = d.oc1x1;
+  const int OCP = 32 * g.ocb, OC1P = 32 * G * g.n_g1;
+  const int ntap = d.kh * d.kw, nkb0 = g.icb * ntap;
+  const size_t n0 = (size_t)g.ocb * nkb0 * 1024, n1 = (size_t)g.n_g1 * g.ocb * G * 1024;
+  std::vector<int8_t> pk(n0 + n1, 0);
+  size_t o = 0;
+  for (int ob = 0; ob < g.ocb; ++ob)
+    for (int icb = 0; icb < g.icb; ++icb)
+      for (int tap = 0; tap < ntap; ++tap)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int b = 0; b < 16; ++b, ++o) {
+            const int oc = 32 * ob + (lane & 31), ic = 32 * icb + 16 * (lane >> 5) + b;
+            if (oc < OC && ic < IC) pk[o] = wei[dfx_blocked_offset(oc, ic, tap / d.kw, tap % d.kw, IC, d.kh, d.kw)];
+          }
+  for (int g1 = 0; g1 < g.n_g1; ++g1)
+    for (int blk = 0; blk < g.ocb; ++blk)
+      for (int cc = 0; cc < G; ++cc)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int b = 0; b < 16; ++b, ++o) {
+            const int oc1 = 32 * G * g1 + G * (lane & 31) + cc;
+            const int oc = 32 * blk + 8 * (b >> 2) + 4 * (lane >> 5) + (b & 3);
+            if (oc1 < OC1 && oc < OC) pk[o] = wei1[dfx_blocked_offset(oc1, oc, 0, 0, OC, 1, 1)];
+          }
+  if (o != n0 + n1) return fail(DFX_ERR_HIP, "internal: direct pack size mismatch");
+  std::vector<int32_t> cst((size_t)3 * (OCP + OC1P), 0);
+  auto put_f = [&](size_t idx, float v) { memcpy(&cst[idx], &v, 4); };
+  bool fast = d.conv0_round_mode == DFX_ROUND_NEAREST && d.conv1_round_mode == DFX_ROUND_NEAREST;
+  std::vector<float> fb0(OC), fb1(OC1);
+  for (int c = 0; c < OC; ++c) {
+    int32_t sum = 0, pos = 0, neg = 0;
+    for (int ic = 0; ic < IC; ++ic)
+      for (int tap = 0; tap < ntap; ++tap) {
+        const int w = wei[dfx_blocked_offset(c, ic, tap / d.kw, tap % d.kw, IC, d.kh, d.kw)];
+        sum += w;
+        (w > 0 ? pos : neg) += w;
+      }
+    cst[c] = 128 * sum;
+    fb0[c] = d.bia0_dt == DFX_UNDEF ? 0.0f : bias_to_f32(bia0, d.bia0_dt, c);
+    const float sc = scales0[d.conv0_nscales > 1 ? c : 0];
+    put_f((size_t)OCP + c, fb0[c]);
+    put_f((size_t)2 * OCP + c, sc);
+    fast = fast && fast_ok_channel(255.0 * std::max(pos, -neg), 128.0 * sum, fb0[c], sc);
+  }
+  for (int c = 0; c < OC1; ++c) {
+    int32_t sum = 0, pos = 0, neg = 0;
+    for (int oc = 0; oc < OC; ++oc) {
+      const int w = wei1[dfx_blocked_offset(c, oc, 0, 0, OC, 1, 1)];
+      sum += w;
+      (w > 0 ? pos : neg) += w;
+    }
+    cst[(size_t)3 * OCP + c] = 128 * sum;
+    fb1[c] = d.bia1_dt == DFX_UNDEF ? 0.0f : bias_to_f32(bia1, d.bia1_dt, c);
+    const float sc = scales1[d.conv1_nscales > 1 ? c : 0];
+    put_f((size_t)3 * OCP + OC1P + c, fb1[c]);
+    put_f((size_t)3 * OCP + 2 * OC1P + c, sc);
+    fast = fast && fast_ok_channel(255.0 * std::max(pos, -neg), 128.0 * sum, fb1[c], sc);
+  }
+  if (const char *e = getenv("DFX_NO_FAST")) fast = fast && atoi(e) == 0;  // testing aid: force the exact path
+  if (fast) {  // the fast path reads comp + bias (an exact f32) from the bias slot
+    for (int c = 0; c < OC; ++c) put_f((size_t)OCP + c, (float)((double)cst[c] + (double)fb0[c]));
+    for (int c = 0; c < OC1; ++c)
+      put_f((size_t)3 * OCP + OC1P + c, (float)((double)cst[(size_t)3 * OCP + c] + (double)fb1[c]));
+  }
+  h->dgeom.fast = fast ? 1 : 0;
+#ifdef DK_DEBUG
+  h->dgeom.wei_bytes = (long long)n0; h->dgeom.wei1_bytes = (long long)n1; h->dgeom.cst_bytes = (long long)cst.size() * 4;
+#endif
+  if (!h->d_wei) HIP_TRY(hipMalloc(&h->d_wei, pk.size() + cst.size() * 4));
+  char *base = (char *)h->d_wei;
+  HIP_TRY(hipMemcpy(base, pk.data(), pk.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(base + pk.size(), cst.data(), cst.size() * 4, hipMemcpyHostToDevice));
+  h->args.wei = (const int8_t *)base;
+  h->args.wei1 = (const int8_t *)(base + n0);
+  h->args.consts = (const float *)(base + pk.size());
+  h->weights_set = true;
+  if (getenv("DFX_DEBUG_PTRS")) fprintf(stderr, "[dfx] direct weights %p..%p (W0 %zu, W1 %zu, consts %zu bytes)\n", (void *)base, (void *)(base + pk.size() + cst.size() * 4), n0, n1, cst.size() * 4);
   return DFX_OK;
 }
 
@@ -934,11 +1156,20 @@ int dfx_conv_query(const dfx_conv_t *h, dfx_conv_info *info) {
   return DFX_OK;
 }
 
+#ifdef DK_DEBUG
+// bounds-checking diagnostic build of conv_direct.cuh: 32 x {offset, size} of the first violation per tag (-1 = none)
+int dfx_debug_read_bounds(dfx_conv_t *h, long long *out) {
+  if (!h || !h->d_prof) return fail(DFX_ERR_STATE, "no debug buffer");
+  HIP_TRY(hipMemcpy(out, h->d_prof, 64 * 8, hipMemcpyDeviceToHost));
+  return DFX_OK;
+}
+#endif
+
 #ifdef DFX_STAMPS
 // diagnostic build only: copies the [grid][8 waves][8] stamp sums of the last launch
 int dfx_debug_read_stamps(dfx_conv_t *h, unsigned long long *out, int max_entries) {
   if (!h || !h->d_prof) return fail(DFX_ERR_STATE, "no stamps");
-  int n = h->grid * (h->variant == DFX_VARIANT_MFMA_STREAM ? 96 : 256);
+  int n = h->grid * (h->variant == DFX_VARIANT_MFMA_STREAM ? (h->direct ? 64 : 96) : 256);
   if (n > max_entries) n = max_entries;
   HIP_TRY(hipMemcpy(out, h->d_prof, (size_t)n * 8, hipMemcpyDeviceToHost));
   return n;

@@ -187,6 +187,36 @@ def test_stream_variant_chunk_parallel_and_split(hip, oracle, monkeypatch, mode)
             hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), info.kernel_name.decode() + " " + case.ident())
 
 
+DIRECT_SHAPES = [
+    C.ConvCase("res3", 2, 128, 14, 14, 128, 512, dst_dt=C.S32),
+    C.ConvCase("res3u", 3, 128, 9, 20, 128, 256, dst_dt=C.U8, wide=True, per_channel0=True, per_channel1=True),
+    C.ConvCase("d64", 2, 64, 12, 10, 64, 64, dst_dt=C.S8, relu1=False),
+    C.ConvCase("d96", 2, 48, 7, 9, 96, 160, dst_dt=C.F32, rm0=1, rm1=1),
+    C.ConvCase("d192s2", 2, 80, 13, 11, 192, 320, stride=(2, 2), dst_dt=C.U8),
+    C.ConvCase("d256k1", 5, 96, 6, 5, 256, 128, k=(1, 1), pad=(0, 0), dst_dt=C.S32),
+    C.ConvCase("d128k5", 1, 16, 9, 9, 128, 96, k=(5, 5), pad=(2, 2), dst_dt=C.U8),
+    C.ConvCase("d7x7", 9, 64, 7, 7, 64, 256, dst_dt=C.S32),
+    C.ConvCase("dw200", 1, 32, 3, 200, 64, 64, dst_dt=C.S32),
+    C.ConvCase("d512", 2, 256, 7, 7, 512, 640, dst_dt=C.U8, wide=True),
+]
+
+
+@pytest.mark.parametrize("grid", ["", "2"])
+def test_direct_weight_kernel(hip, oracle, monkeypatch, grid):
+    """fused ops with >= 64 channels on both sides run on conv_direct.cuh (weights straight from
+    L2 into MFMA operands); also with DFX_NO_FAST (exact requant path) and many units per workgroup."""
+    monkeypatch.setenv("DFX_STREAM_DIRECT", "1")   # (auto only picks it for deep first contractions)
+    if grid:
+        monkeypatch.setenv("DFX_STREAM_GRID", grid)
+    for nofast in ("0", "1"):
+        monkeypatch.setenv("DFX_NO_FAST", nofast)
+        for case in DIRECT_SHAPES + [C.CONFIG3_SMALL, replace(C.CONFIG3_SMALL, dst_dt=C.U8, wide=True)]:
+            data = C.generate(case)
+            got, info = hip.hip_conv(case, data, force_variant=hip.dfa.VARIANT_MFMA_STREAM)
+            assert info.kernel_name.decode().startswith("conv_direct_kernel"), info.kernel_name
+            hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), info.kernel_name.decode() + " " + case.ident())
+
+
 def _random_cases(n, seed, big=False):
     """seeded random shapes inside what the reference's init_conf admits: channels multiples
     of 16, any kernel / stride / padding with a non-empty output"""
