@@ -394,6 +394,7 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
 
   // =========================== compute waves ===========================
   stage_weights();
+  DFX_STAMP(t_staged);  // (diagnostic builds: the stamp waits for this wave's LDS writes)
   __syncthreads();
   const int l31 = lane & 31, h = lane >> 5;
   const float *comp0 = cst, *bias0 = cst + OC, *scale0 = cst + 2 * OC;
@@ -408,6 +409,9 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
 #endif
   DFX_STAMP(t_loop);
   DFX_ACC(4, t_loop - t_entry);  // start-up: weights staging + barrier
+#ifdef DFX_STAMPS
+  const unsigned long long startup_stage = t_staged - t_entry;
+#endif
   int rot = 0;  // tile i of a unit goes to compute wave (rot + i) % MFMA_CW; rot advances by the
                // unit's tile count, so units with fewer than MFMA_CW tiles keep every wave busy
   for (int k = 0;; ++k) {
@@ -633,7 +637,7 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
     if (lane == 0) {
       unsigned long long *o = g.prof + ((size_t)blockIdx.x * 16 + wave) * 16;
       for (int k = 0; k < 8; ++k) o[k] = prof_acc[k];
-      o[8] = t_entry; o[9] = t_end; o[10] = rt; o[11] = rt_entry;
+      o[8] = t_entry; o[9] = t_end; o[10] = rt; o[11] = rt_entry; o[12] = startup_stage;
     }
   }
 #endif

@@ -42,7 +42,7 @@ units = comp[..., 7].mean()
 print("units per team (mean): %.2f (min %.0f max %.0f), tiles per compute wave: %.2f" % (
     units, comp[..., 7].min(), comp[..., 7].max(), comp[..., 6].mean()))
 names = ["wait for tile", "conv0 MFMA", "requant0", "conv1+requant1+stores", "-", "whole unit"]
-print("start-up (entry -> unit loop): mean %.0f cycles" % comp[..., 4].mean())
+print("start-up (entry -> unit loop): mean %.0f cycles, of which this wave's weight staging (loads + LDS writes) %.0f; rest = barrier wait" % (comp[..., 4].mean(), comp[..., 12].mean()))
 life = comp[..., 9] - comp[..., 8]
 print("wave lifetime entry->exit: mean %.0f  min %.0f  max %.0f cycles" % (life.mean(), life.min(), life.max()))
 rt = comp[..., 10]
