@@ -259,61 +259,115 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
   int *full = ctrl + team * 6, *done = full + 2, *unit_of = full + 4;
   unsigned char *team_tiles = tiles + (size_t)team * 2 * g.tile_stride;
 
+  // ---- halo-tile chunk helpers (loader waves; compute waves for the very first tile) ----
+  const v4i x80 = v4i{(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+  // chunk q of a unit's halo tile: LDS row lr = q / row_chunks, chunk c within the row
+  auto load_chunk = [&](const uint8_t *src_n, int y0, int x0, int q) {
+    const int lr = (int)__umulhi((unsigned)q, g.row_magic);
+    const int c = q - lr * g.row_chunks;
+    const int iy = y0 + lr, ix = x0 + c / CP;
+    const bool ok = q < g.tile_chunks && iy >= 0 && iy < a.ih && ix >= 0 && ix < a.iw;
+    // branch-free: out-of-image chunks read offset 0 of the image and are zeroed
+    // (real 0).  32-bit offset off a uniform base.
+    const unsigned off = ok ? (unsigned)((iy * a.iw + ix) * IC + 16 * (c % CP)) : 0u;
+    const v4i v = *reinterpret_cast<const v4i *>(src_n + off);
+    return (ok ? v : v4i{0, 0, 0, 0}) ^ x80;  // stored form: u8 - 128; padding = 0x80
+  };
+  // LDS byte offset of chunk q (unit independent); chunks beyond the tile go to a
+  // 16-byte dump slot right behind it so the write loop needs no predicate
+  auto chunk_lds_off = [&](int q) {
+    const int lr = (int)__umulhi((unsigned)q, g.row_magic);
+    const int c = q - lr * g.row_chunks;
+    const int P = lr * LW + c / CP;
+    return q < g.tile_chunks ? P * IC + 16 * ((c % CP) ^ chunk_swizzle<CP>(P)) : g.tile_chunks * 16;
+  };
+  auto unit_origin = [&](int unit, const uint8_t *&src_n, int &y0, int &x0) {
+    const int n = unit / upi, u = unit - n * upi;
+    const int uyi = u / g.ux, uxi = u - uyi * g.ux;
+    y0 = uyi * g.th - a.pt;
+    x0 = uxi * g.tw - a.pl;
+    src_n = a.src + (size_t)n * a.ih * a.iw * IC;
+  };
+
+  // The FIRST tile of each team is staged cooperatively by the team's 7 compute waves right
+  // after the weights (2-3 chunks per thread, one memory round trip), and published before
+  // the barrier: the loader's own start-up (per-lane staging table, 22-chunk prefetch address
+  // math: ~11 k cycles, measured) used to sit between the barrier and the first MFMA.  The
+  // loader then starts with the team's second unit.  Needs a statically known first unit.
+  const bool coop0 = g.static_rounds >= 1;
+
   // ---- weights + constants: the host keeps them in ONE device buffer laid out
   //      exactly like the LDS image [W0 fragments | W1 fragments | constants], so a
   //      single linear copy stages them.  All global loads of a pass are issued
   //      before the first LDS write: one memory round trip per 128 KB. ----
   auto stage_weights = [&]() {  // called by the 14 compute waves (the loaders hold tile data)
     constexpr int NT = MFMA_TEAMS * MFMA_CW * 64;
-    const int ctid = (team * MFMA_CW + cw) * 64 + lane;
+    constexpr int TT = MFMA_CW * 64;  // threads of one team's compute waves
+    const int ctid = (team * MFMA_CW + cw) * 64 + lane, tctid = cw * 64 + lane;
     const v4i *s = reinterpret_cast<const v4i *>(a.wei);
     v4i *d = reinterpret_cast<v4i *>(smem);
     const int total = OCB * 9 * ICB * 64 + NCB * OCB * 64 + (3 * (OC + OC1) * 4 + 15) / 16;
+    // the team's first tile (coop0): buffer 0, unit = team id; its first 4 chunks per thread
+    // travel together with the weights (one memory round trip for both)
+    const int unit0 = (int)blockIdx.x * MFMA_TEAMS + team;
+    const bool tile0 = coop0 && unit0 < g.total_units;
+    const uint8_t *src_n = a.src;
+    int y0 = 0, x0 = 0;
+    if (tile0) unit_origin(unit0, src_n, y0, x0);
     for (int base = 0; base < total; base += 4 * NT) {
       const int q0 = base + ctid, last = total - 1;
       const v4i t0 = s[min(q0 + 0 * NT, last)];
       const v4i t1 = s[min(q0 + 1 * NT, last)];
       const v4i t2 = s[min(q0 + 2 * NT, last)];
       const v4i t3 = s[min(q0 + 3 * NT, last)];
+      v4i u0 = x80, u1 = x80, u2 = x80, u3 = x80;
+      if (tile0 && base == 0) {
+        u0 = load_chunk(src_n, y0, x0, tctid + 0 * TT);
+        u1 = load_chunk(src_n, y0, x0, tctid + 1 * TT);
+        u2 = load_chunk(src_n, y0, x0, tctid + 2 * TT);
+        u3 = load_chunk(src_n, y0, x0, tctid + 3 * TT);
+      }
       d[min(q0 + 0 * NT, last)] = t0;
       d[min(q0 + 1 * NT, last)] = t1;
       d[min(q0 + 2 * NT, last)] = t2;
       d[min(q0 + 3 * NT, last)] = t3;
+      if (tile0 && base == 0) {
+        *reinterpret_cast<v4i *>(team_tiles + chunk_lds_off(tctid + 0 * TT)) = u0;
+        *reinterpret_cast<v4i *>(team_tiles + chunk_lds_off(tctid + 1 * TT)) = u1;
+        *reinterpret_cast<v4i *>(team_tiles + chunk_lds_off(tctid + 2 * TT)) = u2;
+        *reinterpret_cast<v4i *>(team_tiles + chunk_lds_off(tctid + 3 * TT)) = u3;
+      }
     }
-    if (ctid < MFMA_CTRL_BYTES / 4) ctrl[ctid] = 0;
+    if (tile0) {  // a tile of more than 4 chunks per thread: the rest
+      for (int base = 4 * TT; base < g.tile_chunks; base += 4 * TT) {
+        const int q0 = base + tctid;
+        const v4i t0 = load_chunk(src_n, y0, x0, q0 + 0 * TT);
+        const v4i t1 = load_chunk(src_n, y0, x0, q0 + 1 * TT);
+        const v4i t2 = load_chunk(src_n, y0, x0, q0 + 2 * TT);
+        const v4i t3 = load_chunk(src_n, y0, x0, q0 + 3 * TT);
+        *reinterpret_cast<v4i *>(team_tiles + chunk_lds_off(q0 + 0 * TT)) = t0;
+        *reinterpret_cast<v4i *>(team_tiles + chunk_lds_off(q0 + 1 * TT)) = t1;
+        *reinterpret_cast<v4i *>(team_tiles + chunk_lds_off(q0 + 2 * TT)) = t2;
+        *reinterpret_cast<v4i *>(team_tiles + chunk_lds_off(q0 + 3 * TT)) = t3;
+      }
+    }
+    if (ctid < MFMA_CTRL_BYTES / 4) {
+      // control block: zero, except that with a cooperatively staged first tile (coop0 below)
+      // buffer 0 of each team starts out published: full[0] = 1, unit[0] = the team's unit 0
+      int v = 0;
+      const int ti = ctid / 6, f = ctid - 6 * ti;
+      if (g.static_rounds >= 1 && ti < MFMA_TEAMS) {
+        const int u0 = (int)blockIdx.x * MFMA_TEAMS + ti;
+        if (f == 0) v = 1;
+        if (f == 4) v = u0 < g.total_units ? u0 : -1;
+      }
+      ctrl[ctid] = v;
+    }
   };
 
   if (cw == MFMA_CW) {
     // =========================== loader wave ===========================
-    const v4i x80 = v4i{(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
     v4i pf[MFMA_LC];
-    // chunk q of a unit's halo tile: LDS row lr = q / row_chunks, chunk c within the row
-    auto load_chunk = [&](const uint8_t *src_n, int y0, int x0, int q) {
-      const int lr = (int)__umulhi((unsigned)q, g.row_magic);
-      const int c = q - lr * g.row_chunks;
-      const int iy = y0 + lr, ix = x0 + c / CP;
-      const bool ok = q < g.tile_chunks && iy >= 0 && iy < a.ih && ix >= 0 && ix < a.iw;
-      // branch-free: out-of-image chunks read offset 0 of the image and are zeroed
-      // (real 0).  32-bit offset off a uniform base.
-      const unsigned off = ok ? (unsigned)((iy * a.iw + ix) * IC + 16 * (c % CP)) : 0u;
-      const v4i v = *reinterpret_cast<const v4i *>(src_n + off);
-      return (ok ? v : v4i{0, 0, 0, 0}) ^ x80;  // stored form: u8 - 128; padding = 0x80
-    };
-    // LDS byte offset of chunk q (unit independent); chunks beyond the tile go to a
-    // 16-byte dump slot right behind it so the write loop needs no predicate
-    auto chunk_lds_off = [&](int q) {
-      const int lr = (int)__umulhi((unsigned)q, g.row_magic);
-      const int c = q - lr * g.row_chunks;
-      const int P = lr * LW + c / CP;
-      return q < g.tile_chunks ? P * IC + 16 * ((c % CP) ^ chunk_swizzle<CP>(P)) : g.tile_chunks * 16;
-    };
-    auto unit_origin = [&](int unit, const uint8_t *&src_n, int &y0, int &x0) {
-      const int n = unit / upi, u = unit - n * upi;
-      const int uyi = u / g.ux, uxi = u - uyi * g.ux;
-      y0 = uyi * g.th - a.pt;
-      x0 = uxi * g.tw - a.pl;
-      src_n = a.src + (size_t)n * a.ih * a.iw * IC;
-    };
     // issue-early half: first 64*MFMA_LC chunks of a unit -> registers
 #define DFX_PREFETCH(UNIT)                                                              \
   do {                                                                                  \
@@ -340,16 +394,29 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
       return v;
     };
 
-    int cur = __builtin_amdgcn_readfirstlane(unit_at(0));
-    int nxt_v = unit_at(1);
-    int jn = 2;
-    if (cur < g.total_units) DFX_PREFETCH(cur);  // first tile's loads fly during the weight copy
+    // coop0: the compute waves stage the team's first tile themselves; the loader passes
+    // the barrier at once (nobody waits for its start-up) and begins with the second unit
+    DFX_STAMP(l_pre);
+    if (coop0) __syncthreads();
+    const int j0 = coop0 ? 1 : 0;
+    int cur = __builtin_amdgcn_readfirstlane(unit_at(j0));
+    int nxt_v = unit_at(j0 + 1);
+    int jn = j0 + 2;
+    if (cur < g.total_units) DFX_PREFETCH(cur);  // (!coop0: the first tile's loads fly during the weight copy)
     int wr_off[MFMA_LC];  // (computed while those loads are in flight)
 #pragma unroll
     for (int i = 0; i < MFMA_LC; ++i) wr_off[i] = chunk_lds_off(lane + 64 * i);
-    __syncthreads();  // the only workgroup barrier: weights + control block are in LDS
+    if (!coop0) __syncthreads();  // the only workgroup barrier: weights + control block are in LDS
+    DFX_STAMP(l_post);
+#ifdef DFX_STAMPS
+    if (lane == 0) {  // loader: cycles from entry to its first loop iteration
+      unsigned long long *o = g.prof + ((size_t)blockIdx.x * 16 + wave) * 16;
+      o[13] = l_pre - t_entry;
+      o[14] = l_post - l_pre;
+    }
+#endif
 
-    for (int k = 0;; ++k) {
+    for (int k = j0;; ++k) {
       const int b = k & 1;
       unsigned char *ins = team_tiles + (size_t)b * g.tile_stride;
       // buffer b is free once the 7 compute waves have finished its previous tile

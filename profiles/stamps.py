@@ -44,6 +44,8 @@ print("units per team (mean): %.2f (min %.0f max %.0f), tiles per compute wave: 
 names = ["wait for tile", "conv0 MFMA", "requant0", "conv1+requant1+stores", "-", "whole unit"]
 print("start-up (entry -> unit loop): mean %.0f cycles, of which this wave's weight staging (loads + LDS writes) %.0f; rest = barrier wait" % (comp[..., 4].mean(), comp[..., 12].mean()))
 life = comp[..., 9] - comp[..., 8]
+ld = p[:, :, 7, :]
+print("loader waves: entry -> barrier %.0f cycles (max %.0f), in the barrier %.0f" % (ld[..., 13].mean(), ld[..., 13].max(), ld[..., 14].mean()))
 print("wave lifetime entry->exit: mean %.0f  min %.0f  max %.0f cycles" % (life.mean(), life.min(), life.max()))
 rt = comp[..., 10]
 rte = comp[..., 11]
