@@ -52,6 +52,8 @@ rte = comp[..., 11]
 print("s_memtime ticks per s_memrealtime tick (10 ns): %.2f  => s_memtime runs at %.0f MHz" % ((life / (rt - rte)).mean(), (life / (rt - rte)).mean() * 100))
 print("entry time spread over all compute waves: %.2f us; kernel span first entry -> last exit: %.2f us" % ((rte.max() - rte.min()) / 100.0, (rt.max() - rte.min()) / 100.0))
 print("exit time spread over all compute waves (s_memrealtime @100MHz): %.2f us; per-WG entry spread n/a" % ((rt.max() - rt.min()) / 100.0))
+ex = (rt.max() - rt.reshape(info.grid * 2, -1).max(axis=1)) / 100.0   # per team: idle us before the kernel ends
+print("team idle time before kernel end (us): mean %.2f  percentiles 10/50/90/100: %s  => %.1f%% of the span" % (ex.mean(), [round(float(v), 2) for v in np.percentile(ex, [10, 50, 90, 100])], 100 * ex.mean() / ((rt.max() - rte.min()) / 100.0)))
 tot = comp[..., 5].sum()
 for k, nm in enumerate(names):
     if nm == "-":
