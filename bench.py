@@ -59,6 +59,10 @@ def workloads():
                  "ResNet-50 res4-style block: N=128 14x14 256->256->1024 u8xs8"),
         "res5": (C.ConvCase("res5", 128, 512, 7, 7, 512, 2048, dst_dt=C.U8),
                  "ResNet-50 res5-style block: N=128 7x7 512->512->2048 u8xs8"),
+        "pw256": (C.ConvCase("pw256", 128, 256, 56, 56, 64, 0, k=(1, 1), pad=(0, 0), dst_dt=C.U8),
+                  "ResNet-50 res2 reduce-style unfused 1x1 conv: N=128 56x56 256->64 u8xs8"),
+        "pw1024": (C.ConvCase("pw1024", 128, 1024, 14, 14, 256, 0, k=(1, 1), pad=(0, 0), dst_dt=C.U8),
+                   "ResNet-50 res4 reduce-style unfused 1x1 conv: N=128 14x14 1024->256 u8xs8"),
         "vgg3": (C.ConvCase("vgg3", 64, 256, 56, 56, 256, 0, dst_dt=C.U8),
                  "VGG conv3-style unfused conv: N=64 56x56 256->256 u8xs8"),
         "vgg5": (C.ConvCase("vgg5", 64, 512, 14, 14, 512, 0, dst_dt=C.U8),

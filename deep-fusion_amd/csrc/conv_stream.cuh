@@ -71,6 +71,7 @@ struct StreamGeom {
   int off_tile, off_pxoff, off_mid, off_cst, off_stage;  // LDS byte offsets (weight buffers at 0)
   int fast;             // 1: the fast requant path is valid (host proof, see conv_mfma.cuh store_group)
   int planes;           // 1: one 64-channel input chunk in LDS at a time; n_icc: all chunks resident (staged once per item)
+  unsigned mg_g4, mg_lhw, mg_lw;  // ceil(2^32 / x) for x = 4 * planes, lh * lw, lw (resident-chunk staging)
   int occ_par;          // unfused only: 1 = a work item is (unit, output chunk) instead of a whole unit
 #ifdef DFX_STAMPS
   unsigned long long *prof;  // diagnostic build only: [workgroup][wave][16] cycle sums
@@ -330,19 +331,32 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
           // ---- all input chunks resident: stage them once per work item ----
           if (occ == occ_lo && icc == 0) {
             DFX_STAMP(s0);
-            if (FUSED && ESZ == 1 && G == 4) __syncthreads();  // (staging area aliases the tile, see below)
-            for (int q = tid; q < tile_q * g.planes; q += ST_THREADS) {
-              const int pl = q / tile_q, ql = q - pl * tile_q;
-              const int pos = ql >> 2, j = ql & 3;
-              const int img = pos / lhw, r = pos - img * lhw;
-              const int ly = r / g.lw, lx = r - ly * g.lw;
-              const int iy = ug.iy0 + ly, ix = ug.ix0 + lx;
-              const bool ok = img < ug.nimg && iy >= 0 && iy < a.ih && ix >= 0 && ix < a.iw && 64 * pl + 16 * j < a.ic;
-              const int n_ = min(ug.n0 + img, a.bs - 1), y_ = min(max(iy, 0), a.ih - 1), x_ = min(max(ix, 0), a.iw - 1);
-              const long long o = (((long long)n_ * a.ih + y_) * a.iw + x_) * a.ic + min(64 * pl + 16 * j, a.ic - 16);
-              const v4i v = *reinterpret_cast<const v4i *>(a.src + o);
-              *reinterpret_cast<v4i *>(tile0 + pl * plane_bytes + pos * ST_POS + 16 * (j ^ chunk_swizzle<4>(pos))) =
-                  ok ? v ^ x80 : x80;
+            if (ESZ == 1 && (FUSED ? G == 4 : OCC >= 2)) __syncthreads();  // (store staging aliases the tile, see below)
+            // granule q = position * (4 planes) + plane * 4 + chunk: consecutive threads read
+            // a pixel's channels, then the next pixel's -- whole contiguous rows of src; the
+            // index math uses host-made reciprocals, eight independent loads per pass
+            const int g4 = 4 * g.planes, nq = g.npos * g4;
+            auto fdiv = [](int q, int x, unsigned mg) { return x == 1 ? q : (int)__umulhi((unsigned)q, mg); };
+            for (int q0 = tid; q0 < nq; q0 += 8 * ST_THREADS) {
+              v4i v[8];
+              int lo[8];
+              bool ok[8];
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                const int q = min(q0 + k * ST_THREADS, nq - 1);
+                const int pos = fdiv(q, g4, g.mg_g4), c = q - pos * g4, pl = c >> 2, j = c & 3;
+                const int img = fdiv(pos, lhw, g.mg_lhw), r = pos - img * lhw;
+                const int ly = fdiv(r, g.lw, g.mg_lw), lx = r - ly * g.lw;
+                const int iy = ug.iy0 + ly, ix = ug.ix0 + lx;
+                ok[k] = img < ug.nimg && iy >= 0 && iy < a.ih && ix >= 0 && ix < a.iw && 64 * pl + 16 * j < a.ic;
+                const int n_ = min(ug.n0 + img, a.bs - 1), y_ = min(max(iy, 0), a.ih - 1), x_ = min(max(ix, 0), a.iw - 1);
+                const long long o = (((long long)n_ * a.ih + y_) * a.iw + x_) * a.ic + min(64 * pl + 16 * j, a.ic - 16);
+                v[k] = *reinterpret_cast<const v4i *>(a.src + o);
+                lo[k] = pl * plane_bytes + pos * ST_POS + 16 * (j ^ chunk_swizzle<4>(pos));
+              }
+#pragma unroll
+              for (int k = 0; k < 8; ++k)  // (the clamped repeats at the end rewrite the last granule)
+                *reinterpret_cast<v4i *>(tile0 + lo[k]) = ok[k] ? v[k] ^ x80 : x80;
             }
             __syncthreads();
             DFX_STAMP(s1);
@@ -353,7 +367,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
           DFX_STAMP(s0);
           // the 1-byte store staging area aliases the tile: every wave must be out of the
           // previous unit's epilogue before the new tile lands
-          if (FUSED && ESZ == 1 && G == 4 && occ == 0 && icc == 0) __syncthreads();
+          if (ESZ == 1 && (FUSED ? G == 4 : OCC >= 2) && occ == occ_lo && icc == 0) __syncthreads();
           if (!tv_ready) DFX_T_ISSUE(ug.n0, ug.iy0, ug.ix0, ug.nimg, icc);
           DFX_T_COMMIT();
           tv_ready = false;
@@ -493,8 +507,47 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
               }
           };
           if (DFX_EXP == 2) { if (acc[0][0][0] == 0x12345678) emit0(TT{}, TT{}); }
+          else if (ESZ == 1 && OCC >= 2 && occ + 1 == occ_hi) { /* staged below: every lane takes part */ }
           else if (fast) { if (full) emit0(TT{}, FF{}); else emit0(TT{}, TT{}); }
           else      { if (full) emit0(FF{}, FF{}); else emit0(FF{}, TT{}); }
+        }
+        if constexpr (!FUSED && ESZ == 1 && OCC >= 2) {
+          // 1-byte outputs, the item's last output chunk (the tile is dead after its K loop:
+          // every wave passed the last step's barrier): transpose 32 px x 32*OCC bytes through
+          // LDS and write 16 bytes per lane instead of OCC bytes (see the fused stage)
+          if (DFX_EXP != 2 && occ + 1 == occ_hi) {
+            constexpr int RS = 32 * OCC + 16, C16 = 2 * OCC;  // staging row stride; 16-byte chunks per pixel
+            unsigned char *stg = tile0 + wave * ST_STAGE;
+            unsigned char *dst_b = reinterpret_cast<unsigned char *>(a.dst);
+            const bool relu = a.relu0 || DST == DFX_U8;
+            float zf[OCC];
+#pragma unroll
+            for (int cc = 0; cc < OCC; ++cc) zf[cc] = 0.0f;
+            auto emit0s = [&](auto fast_tag) {
+#pragma unroll
+              for (int pb = 0; pb < PXB; ++pb) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                  int v[OCC];
+#pragma unroll
+                  for (int cc = 0; cc < OCC; ++cc) v[cc] = acc[pb][cc][e] + cp0[cc];
+                  const unsigned pk = pack_group<DST, OCC, decltype(fast_tag)::value>(v, zf, bs0, sc0, relu, a.rm0);
+                  unsigned char *w = stg + (8 * (e >> 2) + (e & 3) + 4 * h) * RS + OCC * l31;
+                  if (OCC == 4) *reinterpret_cast<unsigned *>(w) = pk;
+                  else *reinterpret_cast<unsigned short *>(w) = (unsigned short)pk;
+                }
+#pragma unroll
+                for (int k = 0; k < C16 / 2; ++k) {
+                  const int c = lane + 64 * k, px = c / C16, c16 = c % C16;
+                  const unsigned off = pxoff[32 * (wave * PXB + pb) + px];
+                  const v4i val = *reinterpret_cast<const v4i *>(stg + px * RS + 16 * c16);
+                  const int ch = 32 * OCC * occ + 16 * c16;
+                  if (off != 0xffffffffu && ch < a.oc) DFX_STORE(reinterpret_cast<v4i *>(dst_b + (size_t)(off + ch)), val);
+                }
+              }
+            };
+            if (fast) emit0s(TT{}); else emit0s(FF{});
+          }
         }
       }
       DFX_STAMP(e1);

@@ -404,7 +404,8 @@ static bool pick_stream_geometry(const dfx_conv_desc &d, int OCC, int G, int PXB
   g.s0_steps = s0 * g.n_occ;
   const int WB = fused ? std::max(OCC, G) : OCC;
   const size_t cst_bytes = fused ? round16((size_t)3 * 32 * g.ocb * 4) : 0;
-  const size_t stage_bytes = (fused && G == 4 && dt_size(d.dst_dt) == 1) ? (size_t)4 * ST_STAGE : 0;  // 4 waves
+  // 1-byte store staging, 4 waves (fused: 4-block groups; unfused: chunks of >= 2 blocks)
+  const size_t stage_bytes = (dt_size(d.dst_dt) == 1 && (fused ? G == 4 : OCC >= 2)) ? (size_t)4 * ST_STAGE : 0;
   const size_t fixed = (size_t)3 * 2 * WB * 1024 + 4 * M + (fused ? (size_t)M * g.mid_stride : 0) + cst_bytes;
   const size_t lds_max = 163840;
   // index ranges the kernel keeps in 32 bits / packed fields
@@ -449,6 +450,10 @@ static bool pick_stream_geometry(const dfx_conv_desc &d, int OCC, int G, int PXB
     g.planes = g.n_icc;
   if (const char *e = getenv("DFX_STREAM_PLANES"))  // testing aid: 0 = never, 1 = whenever it fits LDS at all
     g.planes = (atoi(e) && g.n_icc > 1 && fixed + std::max((size_t)g.n_icc * g.npos * ST_POS + 16, stage_bytes) <= lds_max) ? g.n_icc : 1;
+  {
+    auto magic = [](long long x) { return (unsigned)(((1ull << 32) + (unsigned long long)x - 1) / (unsigned long long)x); };
+    g.mg_g4 = magic(4 * g.planes); g.mg_lhw = magic((long long)g.lh * g.lw); g.mg_lw = magic(g.lw);
+  }
   // +16: the staging dump slot; the 1-byte store staging areas alias the tile
   g.off_pxoff = (int)round16((size_t)g.off_tile + std::max((size_t)g.planes * g.npos * ST_POS + 16, stage_bytes));
   g.off_mid = g.off_pxoff + 4 * M;
