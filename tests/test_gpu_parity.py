@@ -74,6 +74,26 @@ def test_generic_variant(hip, oracle, case):
     hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), info.kernel_name.decode())
 
 
+COOP_CASES = [
+    C.ConvCase("coop_u8", 64, 64, 56, 56, 64, 256, dst_dt=C.U8, wide=True),
+    C.ConvCase("coop_s8x", 64, 32, 40, 72, 64, 96, dst_dt=C.S8, relu1=False, rm0=1, rm1=1, per_channel0=True),
+    C.unfused(C.ConvCase("coop_unf", 64, 64, 56, 56, 64, 0, dst_dt=C.S32, relu0=False)),
+    C.ConvCase("coop_p0", 96, 32, 30, 62, 32, 64, pad=(0, 0), dst_dt=C.F32),
+]
+
+
+@pytest.mark.parametrize("case", COOP_CASES, ids=lambda c: c.ident())
+def test_resident_kernel_cooperative_first_tile(hip, oracle, case):
+    """enough units per team that the first ones are owned statically: the compute waves stage
+    each team's first tile together with the weights (conv_mfma.cuh, coop0)."""
+    data = C.generate(case)
+    got, info = hip.hip_conv(case, data)
+    assert info.variant in (hip.dfa.VARIANT_MFMA_FUSED, hip.dfa.VARIANT_MFMA_CONV), info.kernel_name
+    units = case.bs * -(-case.oh // max(info.rows_per_unit, 1))   # (lower bound: x 1 column unit)
+    assert units >= 2 * 2 * info.grid, "shape too small to reach the statically owned first units"
+    hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), info.kernel_name.decode())
+
+
 # streamed-weight MFMA variant (conv_stream.cuh): general shapes -- SURVEY.md 8(f) rank 3
 STREAM_SHAPES = [
     C.ConvCase("s2", 1, 16, 11, 9, 48, 80, stride=(2, 2)),
