@@ -75,6 +75,13 @@ def lib():
     if not os.path.exists(_LIB):
         raise DfxError("libdfx_hip.so is missing: run __graft_entry__.build() "
                        "(there is no CPU fallback for the deep-fusion hot path)")
+    # PyTorch bundles its own HIP runtime under the same soname: when both live in one process
+    # torch's must be loaded first (the other order leaves torch with "No HIP GPUs are
+    # available").  This binding exists for tests / bench.py, which use torch for device memory.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(_LIB)
     vp, i32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
     sig = {
