@@ -35,6 +35,12 @@ GOLDEN_CASES = [
     replace(C.REF_SHAPES[1], dst_dt=C.S32, bia0_dt=C.UNDEF, bia1_dt=C.F32),
     C.unfused(replace(C.SMALL, dst_dt=C.S8, relu0=False)),
     C.unfused(replace(C.SMALL64, dst_dt=C.F32, relu0=True, per_channel0=True)),
+    # general shapes: stride 2, 5x5, 1x1, > 64 channels, 16/48/80 channels
+    C.ConvCase("s2", 1, 16, 11, 9, 48, 80, stride=(2, 2)),
+    C.ConvCase("k5", 1, 16, 9, 9, 16, 16, k=(5, 5), pad=(2, 2), dst_dt=C.S32),
+    C.ConvCase("k1f", 2, 48, 6, 5, 80, 48, k=(1, 1), pad=(0, 0), dst_dt=C.F32, relu1=False),
+    C.ConvCase("ic128", 1, 128, 6, 6, 80, 48, dst_dt=C.S32, wide=True),
+    C.ConvCase("res3", 1, 128, 7, 9, 128, 256, dst_dt=C.U8, wide=True, per_channel0=True, per_channel1=True),
 ]
 
 
