@@ -130,6 +130,24 @@ def load_traffic(workload, dst):
         return None
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without torchrun: run N ranks as children of
+    `python -m torch.distributed.run` (one per GPU, rendezvous on 127.0.0.1), relay what they
+    print (rank 0 prints the JSON line) and return their exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench.py: launching %d ranks: %s" % (n, " ".join(cmd)))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,31 +159,63 @@ def main():
     ap.add_argument("--variant", type=int, default=-1, help="-1 auto, 0 generic, 1/2 resident-weight mfma, 3 streamed-weight mfma")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="OpenMP threads of the CPU baseline (default: min(host cpus, 16) = one GPU's CPU share)")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="testing aid: stop right after the process group is up (exercises the --gpus N "
+                         "launcher and rendezvous without touching a GPU; with DFX_BENCH_BACKEND=gloo)")
     args = ap.parse_args()
 
+    # ---- N > 1 typed as `python bench.py --gpus N`: start the ranks ourselves.  Decided BEFORE
+    #      torch is imported or any HIP call is made: the parent never touches the GPU, the ranks
+    #      are fresh child processes (never an exec of a process that initialised the GPU). ----
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        log("bench.py: WORLD_SIZE=%d but --gpus %d; launch with --nproc-per-node %d or drop WORLD_SIZE"
+            % (world, args.gpus, args.gpus))
+        sys.exit(2)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
     import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("DFX_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of the N>1 path
+        if backend == "nccl":
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+            if not args.rehearse_launch:
+                torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+    if args.rehearse_launch:
+        if world > 1:
+            t = torch.tensor([float(rank)])
+            dist.all_reduce(t)
+            dist.barrier()
+            total = float(t[0])
+        else:
+            total = 0.0
+        if rank == 0:
+            print(json.dumps({"rehearsal": True, "n_gpus": world, "rank_sum": total,
+                              "backend": os.environ.get("DFX_BENCH_BACKEND", "nccl")}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    if world == 1:
+        torch.cuda.set_device(0)
+
     import cases as C
     import hipref
     dfa = importlib.import_module("deep-fusion_amd")
     from dataclasses import replace
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("DFX_BENCH_BACKEND", "nccl")   # "gloo": single-GPU rehearsal of the N>1 path
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-    else:
-        torch.cuda.set_device(0)
-    assert world == args.gpus or world == 1 and args.gpus == 1, \
-        "launch N>1 with torch.distributed.run --nproc-per-node N"
+    if args.workload == "concat":
+        return bench_concat(args, torch, dist, dfa, C, world, rank)
 
     case, desc = workloads()[args.workload]
     if args.dst:
@@ -256,6 +306,89 @@ def main():
                                                dsts[0][:32].cpu().numpy())
         else:
             out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_concat(args, torch, dist, dfa, C, world, rank):
+    """--workload concat: the reference's default bench_concat case
+    (/root/reference/benchmark/bench_concat.cc:226-242: {4,128,244,244}+{4,256,244,244}, post_relu)
+    in --dst s8|s32|f32|u8 (default s8), device resident.  Rotates over enough src/dst sets that
+    the working set exceeds the 256 MiB Infinity Cache.  HBM-bound: algorithmic bytes = read
+    every input once + write dst once = 2 x dst bytes."""
+    np_dt = {"s8": np.int8, "u8": np.uint8, "s32": np.int32, "f32": np.float32}[args.dst or "s8"]
+    t_dt = {np.int8: torch.int8, np.uint8: torch.uint8, np.int32: torch.int32, np.float32: torch.float32}[np_dt]
+    bs, h, w, chans = 4, 244, 244, [128, 256]
+    es = np.dtype(np_dt).itemsize
+    dst_bytes = bs * h * w * sum(chans) * es
+    nbuf = max(3, int(np.ceil(600e6 / (2 * dst_bytes))) + 1)
+    rng = np.random.default_rng(77 + rank)
+    op = dfa.Concat(bs, h, w, chans, np_dt, True)
+    sets = []
+    for b in range(nbuf):
+        if np_dt == np.float32:
+            srcs = [torch.from_numpy(rng.standard_normal((bs, h, w, c)).astype(np.float32)).cuda() for c in chans]
+        else:
+            lo, hi = (0, 256) if np_dt == np.uint8 else (-100, 100)
+            srcs = [torch.from_numpy(rng.integers(lo, hi, (bs, h, w, c)).astype(np_dt)).cuda() for c in chans]
+        sets.append((srcs, torch.empty(op.dst_shape, dtype=t_dt, device="cuda")))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        op.submit(*sets[i % nbuf])
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for i in range(args.steps):
+        op.submit(*sets[i % nbuf])
+    e1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = e0.elapsed_time(e1) / args.steps
+    if world > 1:
+        tt = torch.tensor([elapsed, kern_ms], dtype=torch.float64,
+                          device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, kern_ms = float(tt[0]), float(tt[1])
+    # checker + CPU baseline (oracle = restatement of op_concat.cc:22-72, pinned by test_concat.cc:31-87)
+    cpu = None
+    if rank == 0:
+        from oracle import oracle as orc
+        srcs, dst = sets[(args.steps - 1) % nbuf]
+        h_srcs = [s_.cpu().numpy() for s_ in srcs]
+        ref = orc.concat(h_srcs, True)
+        got = dst.cpu().numpy()
+        assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), "concat output differs from the oracle"
+        if world == 1 and not args.no_cpu_baseline:
+            t1 = time.perf_counter()
+            reps = 0
+            while time.perf_counter() - t1 < 5.0 and reps < 50:
+                orc.concat(h_srcs, True)
+                reps += 1
+            el = time.perf_counter() - t1
+            cpu = {"value": round(bs * reps / el, 2), "unit": "images/sec", "cores": 1, "kind": "port",
+                   "sample": "%d reps of the same {4,384,244,244} concat+relu, scalar C oracle" % reps}
+        achieved = 2 * dst_bytes / (kern_ms * 1e-3) / 1e9
+        out = {"metric": "concat+relu images/sec", "value": round(bs * world * args.steps / elapsed, 1),
+               "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": np.dtype(np_dt).name, "data": "synthetic",
+               "config": {"workload": "concat+relu {4,128,244,244}+{4,256,244,244} NHWC %s "
+                                      "(reference benchmark/bench_concat.cc:226-242)" % np.dtype(np_dt).name,
+                          "buffer_sets_rotated": nbuf, "working_set_bytes": 2 * dst_bytes * nbuf},
+               "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(achieved / HBM_PEAK_GBS, 4),
+                            "traffic": load_traffic("concat", np.dtype(np_dt).name),
+                            "kernel_ms": round(kern_ms, 5), "algorithmic_bytes_per_launch": 2 * dst_bytes},
+               "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

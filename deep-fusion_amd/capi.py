@@ -113,6 +113,7 @@ def lib():
         "dfx_concat_submit_host": (i32, [vp, ctypes.POINTER(vp), vp]),
         "dfx_concat_submit_gathered": (i32, [vp, vp, ctypes.POINTER(ctypes.c_uint64), vp, vp]),
         "dfx_concat_destroy": (i32, [vp]),
+        "dfx_debug_scribble_lds": (i32, [ctypes.c_uint, vp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)

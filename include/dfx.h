@@ -159,6 +159,11 @@ int dfx_concat_submit_gathered(dfx_concat_t *h, const void *gathered_dev,
                                const uint64_t *offsets, void *dst_dev, dfx_stream_t s);
 int dfx_concat_destroy(dfx_concat_t *h);
 
+/* ---- test hooks (not part of the reference's surface; used by tests/ only) ---- */
+/* Overwrites the LDS of every CU with a pattern (asynchronous, on `s`): makes a kernel that
+ * reads LDS before publishing it fail deterministically (tests/test_gpu_first_launch.py). */
+int dfx_debug_scribble_lds(unsigned pattern, dfx_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif
