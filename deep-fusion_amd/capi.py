@@ -34,7 +34,7 @@ class ConvDesc(ctypes.Structure):
 class ConvInfo(ctypes.Structure):
     _fields_ = [("variant", ctypes.c_int32), ("grid", ctypes.c_int32), ("block", ctypes.c_int32),
                 ("lds_bytes", ctypes.c_int32), ("rows_per_unit", ctypes.c_int32),
-                ("reserved", ctypes.c_int32), ("algorithmic_ops", ctypes.c_uint64),
+                ("device", ctypes.c_int32), ("algorithmic_ops", ctypes.c_uint64),
                 ("algorithmic_bytes", ctypes.c_uint64), ("kernel_name", ctypes.c_char * 96)]
 
 
@@ -100,6 +100,11 @@ def lib():
         "dfx_stream_create": (i32, [ctypes.POINTER(vp)]),
         "dfx_stream_destroy": (i32, [vp]),
         "dfx_stream_sync": (i32, [vp]),
+        "dfx_stream_wait_stream": (i32, [vp, vp]),
+        "dfx_event_create": (i32, [ctypes.POINTER(vp)]),
+        "dfx_event_record": (i32, [vp, vp]),
+        "dfx_event_elapsed_ms": (i32, [vp, vp, ctypes.POINTER(ctypes.c_float)]),
+        "dfx_event_destroy": (i32, [vp]),
         "dfx_reorder_oihw_to_blocked": (i32, [vp, vp, i32, i32, i32, i32]),
         "dfx_blocked_offset": (sz, [i32] * 7),
         "dfx_conv_create": (i32, [ctypes.POINTER(ConvDesc), ctypes.POINTER(vp)]),
@@ -114,12 +119,18 @@ def lib():
         "dfx_concat_submit_gathered": (i32, [vp, vp, ctypes.POINTER(ctypes.c_uint64), vp, vp]),
         "dfx_concat_destroy": (i32, [vp]),
         "dfx_debug_scribble_lds": (i32, [ctypes.c_uint, vp]),
+        "dfx_debug_set_tuning": (i32, [ctypes.c_char_p, ctypes.c_char_p]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
         f.restype, f.argtypes = res, args
     _lib = L
     return L
+
+
+def set_tuning(key, value):
+    """testing / tuning switch of the library; value None clears it."""
+    _check(lib().dfx_debug_set_tuning(key.encode(), None if value is None else str(value).encode()))
 
 
 def _check(rc):

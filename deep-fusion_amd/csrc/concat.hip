@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void concat_kernel(ConcatArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = relu_dword(v[e], a.dt);
     }
-    *reinterpret_cast<v4i *>(a.dst + (size_t)id * 16) = v;
+    dfx_store16(reinterpret_cast<v4i *>(a.dst + (size_t)id * 16), v);
   }
 }
 

@@ -390,7 +390,7 @@ __global__ __launch_bounds__(DK_THREADS, 2) void conv_direct_kernel(ConvArgs a, 
                 const unsigned off = pxoff[32 * (pb0 + p) + px];
                 const v4i val = *reinterpret_cast<const v4i *>(stg + px * 144 + 16 * c16);
                 if (off != 0xffffffffu && 128 * g1 + 16 * c16 < a.oc1)
-                  DFX_STORE(reinterpret_cast<v4i *>(dst_b + DK_CHK(11, (long long)(off + 128 * g1 + 16 * c16), 16, g.dst_bytes)), val);
+                  DFX_STORE16(reinterpret_cast<v4i *>(dst_b + DK_CHK(11, (long long)(off + 128 * g1 + 16 * c16), 16, g.dst_bytes)), val);
               }
             }
           } else {

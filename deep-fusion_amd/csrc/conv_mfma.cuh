@@ -7,56 +7,75 @@
 //   infer_conv0conv1                   src/op_conv.cc:140-260
 //
 // Structure
-//  * ONE PERSISTENT WORKGROUP PER CU: 16 waves (4 per SIMD, <= 128 VGPRs: a single
-//    wave issues at most one VALU instruction every ~4-5 cycles, so the requant
-//    epilogue needs the occupancy).  The 3x3 and 1x1 weights, packed in MFMA
-//    fragment order by the host, are copied to LDS ONCE per CU.
-//  * The 16 waves form two independent TEAMS of 7 compute waves + 1 loader wave.
-//    A team works on "units" (TH output rows x TW output columns of one image)
-//    drawn from a device-side queue (one atomicAdd per unit: the balance211 of
-//    op_conv.cc:155-156 made dynamic).  Each team owns TWO input-tile buffers in
-//    LDS.  The loader holds the whole halo tile of the next unit in its registers
-//    (global loads issued early), writes it (xor 0x80, swizzled) into the free
-//    buffer and publishes it with an LDS flag; compute waves consume a buffer and
-//    count themselves off on an LDS counter.  There is no workgroup barrier after
-//    start-up: compute waves never wait for a global load, for the loader's LDS
-//    write, or for each other, so the MFMA, VALU and store phases of different
-//    waves interleave instead of running in lock step.
-//  * conv0 is D0[oc][px] = sum_k W0[oc][k] * X[k][px] with
-//    v_mfma_i32_32x32x32_i8: packed s8 weights are the A operand (rows = oc),
-//    input pixels the B operand (columns = px).  One MFMA eats 32 input channels
-//    of one (kh,kw) tap.  Both operands come from LDS with ds_read_b128: the
-//    weight image is lane-linear, the input halo tile is [row][col][ic] with a
-//    16-byte-chunk XOR swizzle that makes the 64 B/pixel stride conflict free.
-//  * MFMA i8 is signed x signed.  Activations sit in LDS as (u8 xor 0x80) =
-//    u8 - 128, the MFMA chain starts from the inline constant 0, and the
-//    compensation comp0[oc] = 128 * sum_k W0[oc][k] is added as an f32 right after
-//    the int->f32 conversion: both |raw acc| and |comp| are < 2^24 here (K <= 576),
-//    hence exactly representable, and the single f32 add of two exact values is
-//    the correctly rounded sum = exactly what vcvtdq2ps gives on the true s32
-//    accumulator.  Zero padding is the byte 0x80 (= real 0), which keeps one
-//    compensation constant valid at the borders.
+//  * ONE PERSISTENT WORKGROUP PER CU: 16 waves (4 per SIMD, <= 128 VGPRs) = 14 compute
+//    waves + 2 loader waves.  One wave issues at most one vector instruction every
+//    ~4.5 cycles (v_cvt_f32_i32: 7.5; tools/probe/probe_valu3.hip), a SIMD retires one
+//    per ~1.2 cycles: the kernel is bound by per-wave instruction issue, so the design
+//    minimises instructions per MFMA and keeps four waves per SIMD.
+//    The 3x3 and 1x1 weights, packed in MFMA fragment order by the host, are copied to LDS
+//    ONCE per CU.
+//  * Work = "units" (TH output rows x TW output columns of one image).  A CU walks a
+//    sequence of units k = 0, 1, ...: loader wave L owns the units with k % 2 == L (the
+//    first `static_rounds` of them statically, the rest from a device-side queue: the
+//    balance211 of op_conv.cc:155-156 made dynamic), stages the unit's input halo tile into
+//    ring slot k % 4 of LDS (global loads issued one unit ahead, held in registers,
+//    written as u8 xor 0x80 with a column swizzle) and publishes it with an LDS flag.
+//  * The 32-pixel tiles of the published units are CLAIMED by the compute waves from one
+//    LDS counter (one returning ds_add per tile): any wave takes the next tile of the CU,
+//    so the two loaders' streams, partial units and waves on differently loaded SIMDs
+//    balance themselves; a slot is free again when all of its tile claims were counted
+//    off.  There is no workgroup barrier after start-up.
+//  * conv0 is D0[oc][px] = sum_k W0[oc][k] * X[k][px] with v_mfma_i32_32x32x32_i8: packed
+//    s8 weights are the A operand (rows = oc), input pixels the B operand (columns = px).
+//    One MFMA eats 32 input channels of one (kh,kw) tap.  Both operands come from LDS
+//    with ds_read_b128.  The halo tile is [row][col][ic] with the 16-byte chunks of a
+//    pixel XOR-swizzled by a function of its COLUMN only, so a lane needs one base
+//    address per (tap column, ic half) and every tap row is a wave-uniform offset away:
+//    ~30 address instructions per tile instead of ~120.
+//  * MFMA i8 is signed x signed.  Activations sit in LDS as (u8 xor 0x80) = u8 - 128 and
+//    the exact integer compensation comp[oc] = 128 * sum_k W[oc][k] is folded into the
+//    accumulator's initial value (the MFMA's C operand), so the accumulator IS the
+//    reference's s32 accumulator.  Zero padding is the byte 0x80 (= real 0).
+//  * Requantisation, three host-selected modes per stage (dfx_api.hip proves the
+//    preconditions from the actual weights, bias and scales):
+//      exact   the x86 instruction chain op for op (vcvtdq2ps, vaddps, vmulps, vmaxps,
+//              vcvtps2dq incl. its 0x80000000 overflow/NaN result, vpmovusdb/vpmovsdb)
+//      fast    both roundings nearest-even and no value can be NaN or reach +-2^31:
+//              v_cvt_f32_i32, one add of (integer-valued) bias, mul, v_cvt_pk_u8_f32
+//      magic   additionally |acc + bias| is small enough that the int->f32 conversion
+//              can ride on the MFMA for free: the accumulator starts from the BIT PATTERN
+//              of a float constant m whose binade has ulp u, so after the integer MACs
+//              its bits read as the float m + (acc + bias) * u, exactly.  Subtracting m
+//              (one exact add) and multiplying by scale / u (u a power of two, folded into
+//              the scale by the host) gives float(acc + bias) * scale with the reference's
+//              single rounding, without any v_cvt_f32_i32 -- the most expensive
+//              instruction of the chain.  Stage 0 (lane = pixel, register = channel) loads
+//              per-channel start values bits(1.5 * 2^23) + comp + bias from LDS; stage 1 and
+//              the unfused store stage (lane = channel, registers = pixels) start every
+//              accumulator from the inline constant 1/(2*pi) = 0x3E22F983, the one inline
+//              float constant whose mantissa is not zero, which costs no register at all.
+//    All modes are bit-identical to the oracle on the inputs they accept.
 //  * After conv0 a lane holds, for its pixel, 16 accumulators per 32-oc block at
-//    oc = 32r + 8q + 4h + i (h = lane>>5).  They are requantised in registers
-//    (ReLU, scale, round, saturate to u8), packed 4 per dword, and those 16 bytes
-//    per block ARE the A fragment of the 1x1 MFMA because the host packed the
-//    1x1 weights in exactly this k order: the intermediate activation never
-//    leaves the register file (the reference keeps it in xmm registers,
+//    oc = 32r + 8q + 4h + i (h = lane>>5).  They are requantised in registers, packed 4 per
+//    dword, and those 16 bytes per block ARE the A fragment of the 1x1 MFMA because the
+//    host packed the 1x1 weights in exactly this k order: the intermediate activation
+//    never leaves the register file (the reference keeps it in xmm registers,
 //    jit_conv_kernel.cc:275-277).
-//  * conv1 is D1[px][oc1] = sum_oc mid[px][oc] * W1[oc][oc1]: lane = output
-//    channel, registers = pixels, so bias/scale are per-lane constants.  The host
-//    also permutes which channel each MFMA column computes: within a group of G
-//    column blocks lane L owns channels 32G*cg + G*L + {0..G-1}, so every pixel
-//    is written with one G*4-byte (s32/f32) or G-byte (s8/u8) store per lane
-//    and a half-wave writes 128*G (or 32*G) contiguous bytes: whole HBM lines.
-//  * Requantisation has two code paths selected by a wave-uniform flag the host
-//    sets: "fast" (both round modes nearest-even, and the host proved from the
-//    weights that no value can reach +-2^31 or be NaN, so the x86 overflow/NaN
-//    selects are dead) and "exact" (everything else).  Both are bit-identical
-//    to the reference arithmetic on the inputs they accept.
+//  * conv1 is D1[px][oc1] = sum_oc mid[px][oc] * W1[oc][oc1]: lane = output channel,
+//    registers = pixels, so bias/scale are per-lane constants.  The host also permutes
+//    which channel each MFMA column computes: within a group of G column blocks lane L
+//    owns channels 32G*cg + G*L + {0..G-1}, so every pixel is written with one G*4-byte
+//    (s32/f32) or G-byte (s8/u8) store per lane and a half-wave writes 128*G (or 32*G)
+//    contiguous bytes: whole HBM lines.
+//
+// Round-1 note withdrawn: an earlier revision blamed a one-off wrong output on a hardware
+// hazard (an LDS load overwriting the A/B registers of an MFMA issued just before it).  The
+// isolated probe tools/probe/probe_mfma_war.hip shows no such hazard (0 wrong results in
+// 2.6e10 MFMA/load pairs at distance 0..32); see DESIGN.md section 4.1.  The fragment rings
+// below are a software pipeline (bounded prefetch depth), nothing more.
 //
 // Supported here: kh = kw = 3, stride 1, pad in {0,1}, ic/oc in {32,64}, oc1x1 a
-// multiple of 32.  Everything else goes to conv_generic.hip.
+// multiple of 32.  Everything else goes to conv_stream.cuh / conv_direct.cuh.
 #pragma once
 
 #include <type_traits>
@@ -65,21 +84,49 @@
 
 namespace dfx {
 
-constexpr int MFMA_THREADS = 1024;  // 16 waves = 2 teams x (7 compute + 1 loader)
-constexpr int MFMA_TEAMS = 2;
-constexpr int MFMA_CW = 7;          // compute waves per team
-constexpr int MFMA_CTRL_BYTES = 64; // LDS control block: per team full[2], done[2], unit[2]
-constexpr int MFMA_LC = 22;        // 16-byte chunks the loader wave holds per lane (88 VGPRs)
+constexpr int MFMA_THREADS = 1024;  // 16 waves: 14 compute + 2 loaders (waves 7 and 15)
+constexpr int MFMA_TEAMS = 2;       // loader waves = unit streams per CU
+constexpr int MFMA_CW = 7;          // compute waves per loader
+constexpr int MFMA_NB = 4;          // input-tile ring slots in LDS (2 per loader)
+constexpr int MFMA_CTRL_BYTES = 128; // LDS control block, see CTL_* below
+constexpr int MFMA_LC = 22;         // 16-byte chunks the loader wave holds per lane (88 VGPRs)
+constexpr int MFMA_SPIN_LIMIT = 1 << 24;  // bound of every flag wait (~seconds): a protocol error ends the launch
+                                          // with wrong output (the parity tests catch it) instead of hanging the GPU
+
+// requant start values (see header): bit patterns the accumulators start from
+constexpr int MAGIC0_BITS = 0x4B400000;   // 1.5 * 2^23: ulp 1, room for +-2^22
+constexpr float MAGIC0_F = 12582912.0f;
+constexpr int MAGIC1_BITS = 0x3E22F983;   // 1/(2*pi), an inline constant: ulp 2^-26, mantissa 0x22F983
+constexpr int MAGIC1_LO = -0x22F983;      // most negative / positive integer it can absorb
+constexpr int MAGIC1_HI = 0x7FFFFF - 0x22F983;
+
+// Constant area (floats): per conv0 channel A0 | B0 | C0, per 1x1 channel A1 | B1 | C1 (see emit_pair).
+// The B and C of the STORING stage (stage 1 of a fused op, stage 0 of an unfused one) are kept as
+// PAIRS {k, k}: v_pk_add_f32 / v_pk_mul_f32 then take them as plain 64-bit operands.  Broadcasting
+// one 32-bit constant with op_sel instead is not safe on this hardware: the form that takes the HIGH
+// half of a source pair for the low lane (op_sel:[0,1]) returned wrong low results in the last 16
+// lanes of a wave about once per 1e4 epilogue executions (tools/probe/probe_pk_opsel.hip reproduces it
+// in isolation; the form op_sel_hi:[1,0] and scalar arithmetic never did).
+__host__ __device__ constexpr int mfma_cst_floats(int oc, int oc1) { return oc1 ? 3 * oc + 5 * oc1 : 5 * oc; }
+
+// control block in LDS (ints)
+constexpr int CTL_NEXT = 0;   // 64 x the next tile claim of this CU (every lane of a claiming wave adds 1)
+constexpr int CTL_END = 1;    // [2] first k without a unit, per loader (INT_MAX while running)
+constexpr int CTL_FULL = 4;   // [4] generations published into slot s
+constexpr int CTL_DONE = 8;   // [4] 64 x the tile claims counted off on slot s (cumulative)
+constexpr int CTL_INFO = 16;  // [4][4] per slot: dst pixel index of the unit's first pixel, (th << 16) | tw of
+                              // the (possibly clipped) unit, ceil(2^32 / tiles per row) or 0, unused --
+                              // computed once per unit by the loader so that a tile claim costs no division
 
 __device__ __forceinline__ v16i mfma_i8(v4i a, v4i b, v16i c) {
   return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
 }
 
-template <int CP>  // 16-byte chunks per pixel; chunk j of LDS pixel P sits at j ^ swz(P)
-__device__ __forceinline__ int chunk_swizzle(int P) {
-  if (CP == 2) return (P >> 3) & 1;
-  if (CP == 4) return (P >> 2) & 3;
-  return (P >> 1) & 7;  // CP == 8
+template <int CP>  // 16-byte chunks per pixel; chunk j of the pixel in LDS column X sits at j ^ swz(X)
+__device__ __forceinline__ int chunk_swizzle(int X) {
+  if (CP == 2) return (X >> 3) & 1;
+  if (CP == 4) return (X >> 2) & 3;
+  return (X >> 1) & 7;  // CP == 8 (other kernels)
 }
 
 struct MfmaGeom {  // unit decomposition chosen by the host (dfx_api.hip)
@@ -91,14 +138,39 @@ struct MfmaGeom {  // unit decomposition chosen by the host (dfx_api.hip)
   int row_chunks;   // (tw + 2) * (ic / 16)
   int tile_chunks;  // (th + 2) * row_chunks
   unsigned row_magic;  // ceil(2^32 / row_chunks): q / row_chunks == umulhi(q, row_magic)
-  int fast;            // 1: requant fast path is valid (see header comment)
-  int tile_stride;     // bytes between the 2 x MFMA_TEAMS input-tile buffers in LDS
-  int static_rounds;   // units a team owns statically before it turns to the queue
+  unsigned tw_magic;   // ceil(2^32 / tw)
+  int ntu;             // tile claims per unit = tiles of a full unit
+  unsigned ntu_magic;  // ceil(2^32 / ntu) (unused when ntu == 1)
+  int claim_limit;     // ntu * (total_units + 4): no CU can legitimately claim more tiles
+  int mode0, mode1;    // requant mode of stage 0 / stage 1: 0 exact, 1 fast, 2 magic (see header)
+  int tile_stride;     // bytes between the MFMA_NB input-tile slots in LDS
+  int static_rounds;   // units a loader owns statically before it turns to the queue
   int *queue;          // [0] next unit, [1] finished loaders; both 0 between launches
 #ifdef DFX_STAMPS
   unsigned long long *prof;  // diagnostic build only: [workgroup][wave][16] cycle sums
 #endif
+#ifdef DFX_TRACE
+  int *trace;  // diagnostic build only (make trace): host-visible [workgroup][wave][4] progress words
+#endif
 };
+
+#ifdef DFX_TRACE
+// progress word of this wave in host-pinned memory: readable by the host while the kernel runs
+#define DFX_TRACE_AT(code, v0, v1)                                                                      \
+  do {                                                                                                  \
+    if ((int)threadIdx.x == __builtin_amdgcn_readfirstlane((int)threadIdx.x)) { /* first ACTIVE lane */ \
+      int *tr_ = g.trace + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 4;                          \
+      __hip_atomic_fetch_add(tr_ + 3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); /* events so far */ \
+      if ((threadIdx.x & 63) != 0 && tr_[1] == 0) /* sticky: first trace point lane 0 was missing at */   \
+        __hip_atomic_store(tr_ + 1, (int)(code), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);           \
+      (void)(v0);                                                                                       \
+      __hip_atomic_store(tr_ + 2, (int)__builtin_amdgcn_read_exec_lo(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); (void)(v1); \
+      __hip_atomic_store(tr_ + 0, (int)(code), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);            \
+    }                                                                                                   \
+  } while (0)
+#else
+#define DFX_TRACE_AT(code, v0, v1)
+#endif
 
 #ifdef DFX_STAMPS
 // In-kernel stamps (diagnostic build only; never quote this build's run time).
@@ -117,7 +189,7 @@ __device__ __forceinline__ unsigned long long dfx_stamp() {
 #endif
 
 // f32 value of an accumulator before scaling: vcvtdq2ps(acc) + bias, with the
-// u8->s8 compensation folded in as an exact f32 add (see header comment)
+// u8->s8 compensation folded in as an exact f32 add (conv_stream.cuh / conv_direct.cuh)
 __device__ __forceinline__ float acc_to_f32(int raw, float comp, float bias) {
   return __fadd_rn(__fadd_rn(__int2float_rn(raw), comp), bias);
 }
@@ -125,19 +197,21 @@ __device__ __forceinline__ float acc_to_f32(int raw, float comp, float bias) {
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 #ifndef DFX_RING
-#define DFX_RING 4  // conv0 fragment ring depth (see the conv0 loop)
+#define DFX_RING 3  // conv0 fragment prefetch depth (k-steps in flight)
 #endif
 
 // The output is written once and never re-read by this kernel: non-temporal stores
 // keep it from displacing the input rows / weights in L2 and leave fewer dirty lines
 // to write back at the end of the kernel.
 #ifndef DFX_TEMPORAL_STORES
-#define DFX_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#define DFX_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))  // <= 8 bytes
+#define DFX_STORE16(ptr, val) dfx_store16_nt((ptr), (val))             // 16 bytes: see dfx_device.cuh
 #else
 #define DFX_STORE(ptr, val) (*(ptr) = (val))
+#define DFX_STORE16(ptr, val) dfx_store16((ptr), (val))
 #endif
 
-// ---- one pixel's G consecutive channels -> one store.
+// ---- conv_stream.cuh / conv_direct.cuh: one pixel's G consecutive channels -> one store.
 // FAST (host-proven preconditions, dfx_api.hip): both stages round to nearest-even;
 // every value is finite and |f| < 2^31, so the x86 overflow/NaN selects are dead;
 // comp + bias is an exact integer-valued f32 and |acc + bias| < 2^24, so the single
@@ -169,7 +243,7 @@ __device__ __forceinline__ void store_group(unsigned char *p, const int (&acc)[G
   if (DST == DFX_F32) {
 #pragma unroll
     for (int c = 0; c < G; ++c) f[c] = relu ? relu_x86(f[c]) : f[c];
-    if (G == 4) DFX_STORE(reinterpret_cast<v4f *>(p), (v4f{f[0], f[1], f[2], f[3]}));
+    if (G == 4) DFX_STORE16(reinterpret_cast<v4f *>(p), (v4f{f[0], f[1], f[2], f[3]}));
     else if (G == 2) *reinterpret_cast<float2 *>(p) = float2{f[0], f[1]};
     else *reinterpret_cast<float *>(p) = f[0];
   } else if (DST == DFX_S32) {
@@ -179,7 +253,7 @@ __device__ __forceinline__ void store_group(unsigned char *p, const int (&acc)[G
       if (FAST) v[c] = (int)__builtin_rintf(relu ? __builtin_fmaxf(f[c], 0.0f) : f[c]);
       else v[c] = cvt_x86_rt(relu ? relu_x86(f[c]) : f[c], rm);
     }
-    if (G == 4) DFX_STORE(reinterpret_cast<v4i *>(p), (v4i{v[0], v[1], v[2], v[3]}));
+    if (G == 4) DFX_STORE16(reinterpret_cast<v4i *>(p), (v4i{v[0], v[1], v[2], v[3]}));
     else if (G == 2) *reinterpret_cast<int2 *>(p) = int2{v[0], v[1]};
     else *reinterpret_cast<int *>(p) = v[0];
   } else {
@@ -225,8 +299,91 @@ __device__ __forceinline__ unsigned pack_group(const int (&acc)[G], const float 
   return pk;
 }
 
+// ---- this kernel's store stage.  f[] = one pixel's G consecutive channels after scaling -> ReLU,
+// conversion, one typed store ----
+template <int DST, int G, bool FAST>
+__device__ __forceinline__ void store_pixel(unsigned char *p, float (&f)[G], bool relu, int rm) {
+  if (DST == DFX_F32) {
+#pragma unroll
+    for (int c = 0; c < G; ++c) f[c] = relu ? relu_x86(f[c]) : f[c];
+    if (G == 4) DFX_STORE16(reinterpret_cast<v4f *>(p), (v4f{f[0], f[1], f[2], f[3]}));
+    else if (G == 2) *reinterpret_cast<float2 *>(p) = float2{f[0], f[1]};
+    else *reinterpret_cast<float *>(p) = f[0];
+  } else if (DST == DFX_S32) {
+    int v[G];
+#pragma unroll
+    for (int c = 0; c < G; ++c) {
+      if (FAST) v[c] = (int)__builtin_rintf(relu ? __builtin_fmaxf(f[c], 0.0f) : f[c]);
+      else v[c] = cvt_x86_rt(relu ? relu_x86(f[c]) : f[c], rm);
+    }
+    if (G == 4) DFX_STORE16(reinterpret_cast<v4i *>(p), (v4i{v[0], v[1], v[2], v[3]}));
+    else if (G == 2) *reinterpret_cast<int2 *>(p) = int2{v[0], v[1]};
+    else *reinterpret_cast<int *>(p) = v[0];
+  } else {
+    unsigned pk = 0;
+#pragma unroll
+    for (int c = 0; c < G; ++c) {
+      if (FAST && DST == DFX_U8) {
+        pk = __builtin_amdgcn_cvt_pk_u8_f32(f[c], c, pk);
+      } else {
+        const float fr = relu ? (FAST ? __builtin_fmaxf(f[c], 0.0f) : relu_x86(f[c])) : f[c];
+        const int v = FAST ? (int)__builtin_rintf(fr) : cvt_x86_rt(fr, rm);
+        const unsigned b = (DST == DFX_U8) ? sat_u8_bits(v) : ((unsigned)sat_s8(v) & 0xffu);
+        pk |= b << (8 * c);
+      }
+    }
+    if (G == 4) DFX_STORE(reinterpret_cast<unsigned *>(p), pk);
+    else if (G == 2) *reinterpret_cast<unsigned short *>(p) = (unsigned short)pk;
+    else *p = (uint8_t)pk;
+  }
+}
+
+// TWO pixels (accumulator registers e and e + 1, e even: adjacent registers, so the packed f32
+// instructions take them as they stand) x G consecutive channels -> two stores.
+// `acc` are accumulator BITS that started from MAGIC1_BITS; per-lane constants ia, fb, fc:
+//   MODE 2 (magic)  f = (as_float(acc) + fb) * fc        fb = (comp + bias - 2^23 - 0x22F983) * 2^-26,
+//                                                        fc = scale * 2^26
+//   MODE 1 (fast)   f = (float(acc + ia) + fb) * fc      ia = comp - MAGIC1_BITS, fb = bias, fc = scale
+//   MODE 0 (exact)  the same with the x86 conversions and selects
+template <int DST, int G, int MODE>
+__device__ __forceinline__ void emit_pair(unsigned char *p0, unsigned char *p1, const v16i (&acc)[G], int e,
+                                          const int (&ia)[G], const v2f (&fb)[G], const v2f (&fc)[G],
+                                          bool relu, int rm) {
+  float f0[G], f1[G];
+#pragma unroll
+  for (int c = 0; c < G; ++c) {
+    if (MODE == 2) {
+#ifdef DFX_SCALAR_EMIT  // diagnostic variant: the same arithmetic without packed instructions
+      f0[c] = __fmul_rn(__fadd_rn(__int_as_float(acc[c][e]), fb[c][0]), fc[c][0]);
+      f1[c] = __fmul_rn(__fadd_rn(__int_as_float(acc[c][e + 1]), fb[c][0]), fc[c][0]);
+#else
+      v2f x = {__int_as_float(acc[c][e]), __int_as_float(acc[c][e + 1])};
+      x = (x + fb[c]) * fc[c];  // fb[c] = {k, k}, fc[c] = {s, s}: plain 64-bit operands, no op_sel
+      f0[c] = x[0];
+      f1[c] = x[1];
+#endif
+    } else {
+      f0[c] = __fmul_rn(__fadd_rn(__int2float_rn(acc[c][e] + ia[c]), fb[c][0]), fc[c][0]);
+      f1[c] = __fmul_rn(__fadd_rn(__int2float_rn(acc[c][e + 1] + ia[c]), fb[c][0]), fc[c][0]);
+    }
+  }
+  store_pixel<DST, G, MODE != 0>(p0, f0, relu, rm);
+  store_pixel<DST, G, MODE != 0>(p1, f1, relu, rm);
+}
+
+// First MFMA of a chain whose accumulator starts from the inline constant 1/(2*pi) (MAGIC1_BITS).
+// Written as asm because hipcc, given the constant as a v16i splat used by several MFMAs,
+// materialises it in 16 VGPRs per use instead of the inline operand.  hipcc does not look into
+// asm blocks: the wait states it would put between a VALU instruction that writes A / B and the
+// MFMA (it uses 2; tools/probe/probe_mfma_war.hip shows the hazard is real) are in the block.
+__device__ __forceinline__ v16i mfma_i8_from_magic(v4i a, v4i b) {
+  v16i d;
+  asm volatile("s_nop 3\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, 0.15915494" : "=&v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
 // FUSED = false is the unfused conv() overload (reference deepfusion.h:121-129): the same
-// loader / tile machinery and 3x3 MFMA ring, but the contraction is oriented
+// loader / tile machinery and 3x3 MFMA pipeline, but the contraction is oriented
 // D0[px][oc] (A = input pixels, B = weights packed with the channel permutation, G ==
 // OCB) so that lane = output channel and the typed store is coalesced like the 1x1 stage.
 template <int ICB, int OCB, int G, int DST, bool FUSED = true>
@@ -244,32 +401,30 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
   unsigned char *w0s = smem;                                   // [OCB][9][ICB][64 lanes][16 B]
   unsigned char *w1s = w0s + OCB * 9 * ICB * 1024;             // [NCB][OCB][64 lanes][16 B]
   float *cst = reinterpret_cast<float *>(w1s + NCB * OCB * 1024);
-  const int cst_bytes = (3 * (OC + OC1) * 4 + 15) & ~15;
+  const int cst_bytes = (mfma_cst_floats(OC, OC1) * 4 + 15) & ~15;
   int *ctrl = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(cst) + cst_bytes);
   unsigned char *tiles = reinterpret_cast<unsigned char *>(ctrl) + MFMA_CTRL_BYTES;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
-  const int team = wave >> 3, cw = wave & 7;                  // cw == MFMA_CW: the team's loader
+  const int team = wave >> 3, cw = wave & 7;                  // cw == MFMA_CW: loader `team`
   const int LW = g.tw + 2;
   const int upi = g.uy * g.ux;
-  // per-team control words (LDS): full[b] = number of tiles published into buffer b,
-  // done[b] = number of compute-wave completions on buffer b, unit[b] = unit id or -1
-  int *full = ctrl + team * 6, *done = full + 2, *unit_of = full + 4;
-  unsigned char *team_tiles = tiles + (size_t)team * 2 * g.tile_stride;
 
-  // ---- halo-tile chunk helpers (loader waves; compute waves for the very first tile) ----
+  // ---- halo-tile chunk helpers (loader waves; compute waves for the very first tiles) ----
   const v4i x80 = v4i{(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
-  // chunk q of a unit's halo tile: LDS row lr = q / row_chunks, chunk c within the row
+  // chunk q of a unit's halo tile: LDS row lr = q / row_chunks, chunk c within the row.
+  // Branch-free with CLAMPED, always-in-range coordinates: chunks outside the image (and
+  // chunk indices beyond the tile) read a valid pixel of the same image and are replaced by
+  // zeros (real 0 = the stored byte 0x80).
   auto load_chunk = [&](const uint8_t *src_n, int y0, int x0, int q) {
     const int lr = (int)__umulhi((unsigned)q, g.row_magic);
     const int c = q - lr * g.row_chunks;
     const int iy = y0 + lr, ix = x0 + c / CP;
     const bool ok = q < g.tile_chunks && iy >= 0 && iy < a.ih && ix >= 0 && ix < a.iw;
-    // branch-free: out-of-image chunks read offset 0 of the image and are zeroed
-    // (real 0).  32-bit offset off a uniform base.
-    const unsigned off = ok ? (unsigned)((iy * a.iw + ix) * IC + 16 * (c % CP)) : 0u;
+    const int cy = min(max(iy, 0), a.ih - 1), cx = min(max(ix, 0), a.iw - 1);
+    const unsigned off = (unsigned)((cy * a.iw + cx) * IC + 16 * (c % CP));
     const v4i v = *reinterpret_cast<const v4i *>(src_n + off);
     return (ok ? v : v4i{0, 0, 0, 0}) ^ x80;  // stored form: u8 - 128; padding = 0x80
   };
@@ -278,8 +433,8 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
   auto chunk_lds_off = [&](int q) {
     const int lr = (int)__umulhi((unsigned)q, g.row_magic);
     const int c = q - lr * g.row_chunks;
-    const int P = lr * LW + c / CP;
-    return q < g.tile_chunks ? P * IC + 16 * ((c % CP) ^ chunk_swizzle<CP>(P)) : g.tile_chunks * 16;
+    const int X = c / CP;
+    return q < g.tile_chunks ? (lr * LW + X) * IC + 16 * ((c % CP) ^ chunk_swizzle<CP>(X)) : g.tile_chunks * 16;
   };
   auto unit_origin = [&](int unit, const uint8_t *&src_n, int &y0, int &x0) {
     const int n = unit / upi, u = unit - n * upi;
@@ -289,12 +444,38 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
     src_n = a.src + (size_t)n * a.ih * a.iw * IC;
   };
 
-  // The FIRST tile of each team is staged cooperatively by the team's 7 compute waves right
-  // after the weights (2-3 chunks per thread, one memory round trip), and published before
-  // the barrier: the loader's own start-up (per-lane staging table, 22-chunk prefetch address
-  // math: ~11 k cycles, measured) used to sit between the barrier and the first MFMA.  The
-  // loader then starts with the team's second unit.  Needs a statically known first unit.
+  // what a compute wave needs to know about a unit (the loader computes it once per unit)
+  auto unit_info = [&](int unit, int &pix0, int &thtw, int &tprm) {
+    const int n = unit / upi, u = unit - n * upi;
+    const int uyi = u / g.ux, uxi = u - uyi * g.ux;
+    const int y0 = uyi * g.th, x0 = uxi * g.tw;
+    const int th = min(g.th, a.oh - y0), tw = min(g.tw, a.ow - x0);
+    const int tpr = (tw + 31) >> 5;
+    pix0 = (n * a.oh + y0) * a.ow + x0;
+    thtw = (th << 16) | tw;
+    tprm = tpr > 1 ? (int)(((1ull << 32) + tpr - 1) / tpr) : 0;
+  };
+
+  // The FIRST tile of each loader's stream (k = 0, 1) is staged cooperatively by 7 compute
+  // waves each right after the weights (2-3 chunks per thread, one memory round trip), and
+  // published before the barrier: the loader's own start-up (per-lane staging table,
+  // 22-chunk prefetch address math) used to sit between the barrier and the first MFMA.
+  // The loaders then start with k = 2, 3.  Needs statically known first units.
   const bool coop0 = g.static_rounds >= 1;
+
+  // LDS control words are read and written by WHOLE waves (every lane the same word, the same
+  // value) and every loaded value goes through readfirstlane, so that all control flow below is
+  // scalar: hipcc (ROCm 7.2) otherwise treats the per-lane results of the atomic loads as
+  // divergent, wraps the claim loop in exec-mask bookkeeping and -- with an `if (lane == 0)`
+  // around the claiming atomic -- left lane 0 masked off after the first tile (the wave then
+  // re-claimed tile 0 forever; found with the progress-trace build, profiles/debug/trace_hang.py).
+  auto ctl_load = [&](int idx) {
+    return __builtin_amdgcn_readfirstlane(
+        __hip_atomic_load(ctrl + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+  };
+  auto ctl_store = [&](int idx, int v) {
+    __hip_atomic_store(ctrl + idx, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
 
   // ---- weights + constants: the host keeps them in ONE device buffer laid out
   //      exactly like the LDS image [W0 fragments | W1 fragments | constants], so a
@@ -302,13 +483,14 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
   //      before the first LDS write: one memory round trip per 128 KB. ----
   auto stage_weights = [&]() {  // called by the 14 compute waves (the loaders hold tile data)
     constexpr int NT = MFMA_TEAMS * MFMA_CW * 64;
-    constexpr int TT = MFMA_CW * 64;  // threads of one team's compute waves
+    constexpr int TT = MFMA_CW * 64;  // threads of the 7 compute waves that stage one first tile
     const int ctid = (team * MFMA_CW + cw) * 64 + lane, tctid = cw * 64 + lane;
     const v4i *s = reinterpret_cast<const v4i *>(a.wei);
     v4i *d = reinterpret_cast<v4i *>(smem);
-    const int total = OCB * 9 * ICB * 64 + NCB * OCB * 64 + (3 * (OC + OC1) * 4 + 15) / 16;
-    // the team's first tile (coop0): buffer 0, unit = team id; its first 4 chunks per thread
-    // travel together with the weights (one memory round trip for both)
+    const int total = OCB * 9 * ICB * 64 + NCB * OCB * 64 + (mfma_cst_floats(OC, OC1) * 4 + 15) / 16;
+    // first tile of stream `team` (coop0): ring slot `team`, unit blockIdx * 2 + team; its first
+    // 4 chunks per thread travel together with the weights (one memory round trip for both)
+    unsigned char *slot = tiles + (size_t)team * g.tile_stride;
     const int unit0 = (int)blockIdx.x * MFMA_TEAMS + team;
     const bool tile0 = coop0 && unit0 < g.total_units;
     const uint8_t *src_n = a.src;
@@ -332,10 +514,10 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
       d[min(q0 + 2 * NT, last)] = t2;
       d[min(q0 + 3 * NT, last)] = t3;
       if (tile0 && base == 0) {
-        *reinterpret_cast<v4i *>(team_tiles + chunk_lds_off(tctid + 0 * TT)) = u0;
-        *reinterpret_cast<v4i *>(team_tiles + chunk_lds_off(tctid + 1 * TT)) = u1;
-        *reinterpret_cast<v4i *>(team_tiles + chunk_lds_off(tctid + 2 * TT)) = u2;
-        *reinterpret_cast<v4i *>(team_tiles + chunk_lds_off(tctid + 3 * TT)) = u3;
+        *reinterpret_cast<v4i *>(slot + chunk_lds_off(tctid + 0 * TT)) = u0;
+        *reinterpret_cast<v4i *>(slot + chunk_lds_off(tctid + 1 * TT)) = u1;
+        *reinterpret_cast<v4i *>(slot + chunk_lds_off(tctid + 2 * TT)) = u2;
+        *reinterpret_cast<v4i *>(slot + chunk_lds_off(tctid + 3 * TT)) = u3;
       }
     }
     if (tile0) {  // a tile of more than 4 chunks per thread: the rest
@@ -345,28 +527,38 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
         const v4i t1 = load_chunk(src_n, y0, x0, q0 + 1 * TT);
         const v4i t2 = load_chunk(src_n, y0, x0, q0 + 2 * TT);
         const v4i t3 = load_chunk(src_n, y0, x0, q0 + 3 * TT);
-        *reinterpret_cast<v4i *>(team_tiles + chunk_lds_off(q0 + 0 * TT)) = t0;
-        *reinterpret_cast<v4i *>(team_tiles + chunk_lds_off(q0 + 1 * TT)) = t1;
-        *reinterpret_cast<v4i *>(team_tiles + chunk_lds_off(q0 + 2 * TT)) = t2;
-        *reinterpret_cast<v4i *>(team_tiles + chunk_lds_off(q0 + 3 * TT)) = t3;
+        *reinterpret_cast<v4i *>(slot + chunk_lds_off(q0 + 0 * TT)) = t0;
+        *reinterpret_cast<v4i *>(slot + chunk_lds_off(q0 + 1 * TT)) = t1;
+        *reinterpret_cast<v4i *>(slot + chunk_lds_off(q0 + 2 * TT)) = t2;
+        *reinterpret_cast<v4i *>(slot + chunk_lds_off(q0 + 3 * TT)) = t3;
       }
     }
     if (ctid < MFMA_CTRL_BYTES / 4) {
-      // control block: zero, except that with a cooperatively staged first tile (coop0 below)
-      // buffer 0 of each team starts out published: full[0] = 1, unit[0] = the team's unit 0
+      // control block: zero; "no end seen yet"; with cooperatively staged first tiles, slots 0
+      // and 1 start out published (or their stream is marked empty)
       int v = 0;
-      const int ti = ctid / 6, f = ctid - 6 * ti;
-      if (g.static_rounds >= 1 && ti < MFMA_TEAMS) {
-        const int u0 = (int)blockIdx.x * MFMA_TEAMS + ti;
-        if (f == 0) v = 1;
-        if (f == 4) v = u0 < g.total_units ? u0 : -1;
+      if (ctid == CTL_END || ctid == CTL_END + 1) {
+        v = 0x7fffffff;
+        if (coop0 && (int)blockIdx.x * MFMA_TEAMS + (ctid - CTL_END) >= g.total_units) v = ctid - CTL_END;
+      }
+      if (coop0 && (ctid == CTL_FULL || ctid == CTL_FULL + 1) &&
+          (int)blockIdx.x * MFMA_TEAMS + (ctid - CTL_FULL) < g.total_units) v = 1;
+      if (coop0 && ctid >= CTL_INFO && ctid < CTL_INFO + 8) {  // slots 0, 1: the statically owned first units
+        const int u0 = (int)blockIdx.x * MFMA_TEAMS + ((ctid - CTL_INFO) >> 2);
+        if (u0 < g.total_units) {
+          int i0, i1, i2;
+          unit_info(u0, i0, i1, i2);
+          const int f = (ctid - CTL_INFO) & 3;
+          v = f == 0 ? i0 : f == 1 ? i1 : f == 2 ? i2 : 0;
+        }
       }
       ctrl[ctid] = v;
     }
   };
 
   if (cw == MFMA_CW) {
-    // =========================== loader wave ===========================
+    // =========================== loader wave `team` ===========================
+    // owns k = team, team + 2, ...: ring slot k % 4 = 2 * (j & 1) + team for its j-th unit
     v4i pf[MFMA_LC];
     // issue-early half: first 64*MFMA_LC chunks of a unit -> registers
 #define DFX_PREFETCH(UNIT)                                                              \
@@ -379,8 +571,8 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
     _Pragma("unroll") for (int i = 0; i < MFMA_LC; ++i) pf[i] =                         \
         load_chunk(src_n_, y0_, x0_, lq_ + 64 * i);                                     \
   } while (0)
-    // Unit sequence of this team: the first `static_rounds` units are owned
-    // statically (round j -> unit j*T + team id; no atomic: 2 x gridDim loaders
+    // Unit sequence of this loader: the first `static_rounds` units are owned
+    // statically (round j -> unit j*T + stream id; no atomic: 2 x gridDim loaders
     // hammering one queue word at kernel start cost ~12 us), the rest come from the
     // device-side queue.  Draws are device-scope atomics that take microseconds to
     // return: one is kept in flight and only broadcast (readfirstlane = wait) when needed.
@@ -394,8 +586,8 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
       return v;
     };
 
-    // coop0: the compute waves stage the team's first tile themselves; the loader passes
-    // the barrier at once (nobody waits for its start-up) and begins with the second unit
+    // coop0: the compute waves stage this stream's first tile themselves; the loader passes
+    // the barrier at once (nobody waits for its start-up) and begins with its second unit
     DFX_STAMP(l_pre);
     if (coop0) __syncthreads();
     const int j0 = coop0 ? 1 : 0;
@@ -416,30 +608,40 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
     }
 #endif
 
-    for (int k = j0;; ++k) {
-      const int b = k & 1;
-      unsigned char *ins = team_tiles + (size_t)b * g.tile_stride;
-      // buffer b is free once the 7 compute waves have finished its previous tile
-      while (__hip_atomic_load(done + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < MFMA_CW * (k >> 1))
-        __builtin_amdgcn_s_sleep(2);
+    DFX_TRACE_AT(100, cur, j0);
+    for (int j = j0;; ++j) {
+      const int s = 2 * (j & 1) + team, gen = j >> 1;
+      DFX_TRACE_AT(101, cur, j);
+      unsigned char *ins = tiles + (size_t)s * g.tile_stride;
       const bool valid = cur < g.total_units;
-      if (valid) {
-#pragma unroll
-        for (int i = 0; i < MFMA_LC; ++i)   // write-late half of the staging
-          *reinterpret_cast<v4i *>(ins + wr_off[i]) = pf[i];
-        if (g.tile_chunks > 64 * MFMA_LC) {  // oversized tile: the rest is staged synchronously
-          const uint8_t *src_n; int y0, x0;
-          unit_origin(cur, src_n, y0, x0);
-          for (int q = 64 * MFMA_LC + lane; q < g.tile_chunks; q += 64)
-            *reinterpret_cast<v4i *>(ins + chunk_lds_off(q)) = load_chunk(src_n, y0, x0, q);
-        }
+      if (!valid) {  // this stream has ended at k = 2j + team (a stream that coop0 found empty is marked already)
+        if (!(coop0 && j == 1 && tg >= g.total_units)) ctl_store(CTL_END + team, 2 * j + team);
+        break;
       }
-      if (lane == 0) unit_of[b] = valid ? cur : -1;
+      // slot s is free once every tile claim of its previous generation was counted off
+      for (int spin = 0; spin < MFMA_SPIN_LIMIT && ctl_load(CTL_DONE + s) < 64 * g.ntu * gen; ++spin)
+        __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+      for (int i = 0; i < MFMA_LC; ++i)   // write-late half of the staging
+        *reinterpret_cast<v4i *>(ins + wr_off[i]) = pf[i];
+      if (g.tile_chunks > 64 * MFMA_LC) {  // oversized tile: the rest is staged synchronously
+        const uint8_t *src_n; int y0, x0;
+        unit_origin(cur, src_n, y0, x0);
+        for (int q = 64 * MFMA_LC + lane; q < g.tile_chunks; q += 64)
+          *reinterpret_cast<v4i *>(ins + chunk_lds_off(q)) = load_chunk(src_n, y0, x0, q);
+      }
+      DFX_TRACE_AT(102, cur, j);
+      {
+        int i0, i1, i2;
+        unit_info(cur, i0, i1, i2);
+        ctrl[CTL_INFO + 4 * s + 0] = i0;
+        ctrl[CTL_INFO + 4 * s + 1] = i1;
+        ctrl[CTL_INFO + 4 * s + 2] = i2;
+      }
       // publish: LDS executes a wave's DS instructions in order; the release makes the
       // compiler keep them ahead of the flag store and waits for them to complete
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // all lanes' tile writes first
-      if (lane == 0) __hip_atomic_store(full + b, (k >> 1) + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (!valid) break;
+      ctl_store(CTL_FULL + s, gen + 1);
       cur = __builtin_amdgcn_readfirstlane(nxt_v);
       nxt_v = unit_at(jn++);
       if (cur < g.total_units) DFX_PREFETCH(cur);
@@ -448,6 +650,7 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
     // last loader out re-arms the queue for the next launch.  The draw still in
     // flight must have been performed before this loader counts itself out, or it
     // could land after the reset.
+    DFX_TRACE_AT(103, cur, 0);
     const int pending = __builtin_amdgcn_readfirstlane(nxt_v);
     if (lane == 0 && pending >= 0) {
       const int fin = atomicAdd(g.queue + 1, 1);
@@ -456,20 +659,27 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
         atomicExch(g.queue + 1, 0);
       }
     }
+    DFX_TRACE_AT(199, 0, 0);
     return;
   }
 
   // =========================== compute waves ===========================
+  DFX_TRACE_AT(1, 0, 0);
   stage_weights();
+  DFX_TRACE_AT(2, 0, 0);
   DFX_STAMP(t_staged);  // (diagnostic builds: the stamp waits for this wave's LDS writes)
   __syncthreads();
   const int l31 = lane & 31, h = lane >> 5;
-  const float *comp0 = cst, *bias0 = cst + OC, *scale0 = cst + 2 * OC;
-  const float *comp1 = cst + 3 * OC, *bias1 = cst + 3 * OC + OC1, *scale1 = cst + 3 * OC + 2 * OC1;
+  // constants in LDS: [A0 | B0 | C0] per conv0 channel, [A1 | B1 | C1] per 1x1 channel
+  const int *ia0 = reinterpret_cast<const int *>(cst);
+  const float *fb0 = cst + OC, *fc0 = cst + 2 * OC;                    // fused: scalars per conv0 channel
+  const v2f *pb0 = reinterpret_cast<const v2f *>(cst + OC), *pc0 = reinterpret_cast<const v2f *>(cst + 3 * OC);  // unfused: pairs
+  const int *ia1 = reinterpret_cast<const int *>(cst + 3 * OC);
+  const v2f *pb1 = reinterpret_cast<const v2f *>(cst + 3 * OC + OC1), *pc1 = reinterpret_cast<const v2f *>(cst + 3 * OC + 3 * OC1);
   const bool relu1 = (FUSED ? a.relu1 : a.relu0) || DST == DFX_U8;  // ReLU of the stage that stores
-  const bool fast = g.fast != 0;
-  const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const int mode0 = g.mode0, mode1 = g.mode1;
   const unsigned row_bytes = (unsigned)(FUSED ? OC1 : OC) * ESZ;  // dst bytes per pixel
+  const int lds_row = LW * IC;                                    // bytes per halo-tile row in LDS
 
 #ifdef DFX_STAMPS
   unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -479,72 +689,111 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
 #ifdef DFX_STAMPS
   const unsigned long long startup_stage = t_staged - t_entry;
 #endif
-  int rot = 0;  // tile i of a unit goes to compute wave (rot + i) % MFMA_CW; rot advances by the
-               // unit's tile count, so units with fewer than MFMA_CW tiles keep every wave busy
-  for (int k = 0;; ++k) {
-    const int b = k & 1;
-    const unsigned char *ins = team_tiles + (size_t)b * g.tile_stride;
+  DFX_TRACE_AT(3, 0, 0);
+  // Tile claims: every lane adds 1 to the CU's counter, so one claim moves it by 64 and any lane's
+  // old value >> 6 is the claim (whether hipcc folds the 64 adds into one ds_add_rtn of 64, as it
+  // does, or not).  LDS round trips take ~1 k cycles while 14 waves stream fragments, so a wave
+  // draws its NEXT claim at the start of a tile and only looks at the result when the tile is done;
+  // a claim is always processed by the wave that drew it (a wave that leaves holds one beyond the end).
+  auto draw = [&]() {
+    return __hip_atomic_fetch_add(ctrl + CTL_NEXT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  int t_ahead = draw();
+  for (;;) {
     DFX_STAMP(c0);
-    while (__hip_atomic_load(full + b, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (k >> 1) + 1)
+    const int t = __builtin_amdgcn_readfirstlane(t_ahead) >> 6;
+    t_ahead = draw();
+    DFX_TRACE_AT(4, t, g.claim_limit);
+    if (t > g.claim_limit) break;  // cannot happen (a CU never claims more than every tile of the op): keeps a logic error from hanging the GPU
+    const int k = g.ntu == 1 ? t : (int)__umulhi((unsigned)t, g.ntu_magic);  // (ceil(2^32 / 1) does not fit 32 bits)
+    const int ti = t - k * g.ntu;
+    const int s = k & (MFMA_NB - 1), gen = k >> 2, p = k & 1;
+    // one batch of LDS reads per look: FULL first, then the slot's unit record (LDS serves a wave's
+    // reads in order, and the loader wrote the record before FULL), then the stream's END
+    bool have = false;
+    v4i info = {0, 0, 0, 0};
+    for (int spin = 0; spin < MFMA_SPIN_LIMIT; ++spin) {  // (bounded: a protocol error must not hang the GPU)
+      const int full = __hip_atomic_load(ctrl + CTL_FULL + s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      info = *reinterpret_cast<const volatile v4i *>(ctrl + CTL_INFO + 4 * s);
+      const int end = __hip_atomic_load(ctrl + CTL_END + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (__builtin_amdgcn_readfirstlane(full) >= gen + 1) { have = true; break; }
+      if (__builtin_amdgcn_readfirstlane(end) <= k) break;
       __builtin_amdgcn_s_sleep(1);
+    }
+    DFX_TRACE_AT(5, t, have);
     DFX_STAMP(c1);
-    DFX_ACC(0, c1 - c0);  // wait for the tile
-    const int unit = __builtin_amdgcn_readfirstlane(unit_of[b]);
-    if (unit < 0) break;
-
-    const int n = unit / upi, u = unit - n * upi;
-    const int uyi = u / g.ux, uxi = u - uyi * g.ux;
-    const int y0 = uyi * g.th, x0 = uxi * g.tw;
-    const int th = min(g.th, a.oh - y0), tw = min(g.tw, a.ow - x0);
+    DFX_ACC(0, c1 - c0);  // claim + wait for the tile's unit
+    if (!have) {  // stream p has no k-th unit; done when the other stream has none for k + 1 either
+      if (ctl_load(CTL_END + (p ^ 1)) <= k + 1) break;
+      continue;
+    }
+    const unsigned char *ins = tiles + (size_t)s * g.tile_stride;
+    const int pix0 = __builtin_amdgcn_readfirstlane(info[0]);
+    const int thtw = __builtin_amdgcn_readfirstlane(info[1]);
+    const int th = thtw >> 16, tw = thtw & 0xffff;
     const int npx = th * tw;
     const int tiles_per_row = (tw + 31) >> 5;
     const int ntiles = g.linear ? (npx + 31) >> 5 : th * tiles_per_row;
 
-    int t0 = cw - rot;
-    if (t0 < 0) t0 += MFMA_CW;
-    rot = (rot + ntiles) % MFMA_CW;
-    for (int t = t0; t < ntiles; t += MFMA_CW) {
+    DFX_TRACE_AT(6, pix0, ntiles);
+    if (ti < ntiles) {
       // pixel of this lane (conv0 column) and the tile's output base (wave-uniform)
       int ty, tx, nvalid;
       size_t obase;  // dst pixel index of px_local == 0
       if (g.linear) {
-        nvalid = min(32, npx - 32 * t);
-        const int pc = 32 * t + min(l31, nvalid - 1);
-        ty = pc / tw;
+        nvalid = min(32, npx - 32 * ti);
+        const int pc = 32 * ti + min(l31, nvalid - 1);
+        ty = tw == 1 ? pc : (int)__umulhi((unsigned)pc, g.tw_magic);  // tw == g.tw in linear mode
         tx = pc - ty * tw;
-        obase = ((size_t)n * a.oh + y0) * a.ow + 32 * t;
+        obase = (size_t)pix0 + 32 * ti;
       } else {
-        const int tr = t / tiles_per_row, tc = t - tr * tiles_per_row;
+        const int tprm = __builtin_amdgcn_readfirstlane(info[2]);
+        const int tr = tprm ? (int)__umulhi((unsigned)ti, (unsigned)tprm) : ti, tc = ti - tr * tiles_per_row;
         nvalid = min(32, tw - 32 * tc);
         ty = tr;
         tx = 32 * tc + min(l31, nvalid - 1);
-        obase = ((size_t)n * a.oh + y0 + tr) * a.ow + x0 + 32 * tc;
+        obase = (size_t)pix0 + (size_t)tr * a.ow + 32 * tc;
       }
-      const int Pb = ty * LW + tx;
       // Lane-constant LDS offsets are made opaque once per tile: otherwise LICM
       // hoists every weight / constant fragment read out of the tile loop and
       // keeps >200 VGPRs live across it (spills).
       int lane16 = lane * 16, h4 = 4 * h, lch = G * l31;
       asm volatile("" : "+v"(lane16), "+v"(h4), "+v"(lch));
 
+      DFX_TRACE_AT(60, ty, tx);
       DFX_STAMP(c2);
       // ---- conv0: 9 taps x ICB k-steps x OCB row blocks ----
-      // Explicit RD-deep fragment ring: the fragments of k-step s+RD-1 are fetched right
-      // after the MFMAs of step s were issued, into the registers last read by the
-      // MFMAs of step s-1.  An LDS load must never target a register that a just-issued
-      // MFMA still has to read as A/B operand (see the note at the 1x1 stage); here at
-      // least OCB MFMAs separate the two.  sched_barrier keeps hipcc from re-mixing.
-      v16i acc0[OCB];
+      // per-lane B-fragment addresses for tap row 0: one per (tap column, ic half); tap rows 1, 2
+      // are lds_row bytes further each.  The chunk swizzle depends on the LDS column only.
+      int bb[3][ICB];
 #pragma unroll
-      for (int r = 0; r < OCB; ++r) acc0[r] = zero16;
+      for (int dx = 0; dx < 3; ++dx) {
+        const int X = tx + dx;
+        const int pb = (ty * LW + X) * IC, sw = chunk_swizzle<CP>(X);
+#pragma unroll
+        for (int c = 0; c < ICB; ++c) bb[dx][c] = pb + 16 * ((2 * c + h) ^ sw);
+      }
+      v16i acc0[OCB];
+      if (FUSED) {  // start values per channel from LDS (0 / comp / bits(1.5 * 2^23) + comp + bias)
+#pragma unroll
+        for (int r = 0; r < OCB; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const v4i iv = *reinterpret_cast<const v4i *>(ia0 + 32 * r + 8 * q + h4);
+            acc0[r][4 * q + 0] = iv[0]; acc0[r][4 * q + 1] = iv[1];
+            acc0[r][4 * q + 2] = iv[2]; acc0[r][4 * q + 3] = iv[3];
+          }
+      }  // (unfused: the first MFMA of each chain starts from the inline constant MAGIC1_BITS)
       {
+        // software pipeline: the fragments of k-step s+RD-1 are fetched right after the
+        // MFMAs of step s were issued (bounded prefetch depth; sched_barrier keeps hipcc
+        // from hoisting all 54 loads to the top and spilling)
         constexpr int NS = 9 * ICB;  // k-steps
-        constexpr int RD = DFX_RING;  // ring slots; fragments are fetched RD-1 steps ahead
+        constexpr int RD = DFX_RING;
         v4i fb[RD], fw[RD][OCB];
         auto fetch = [&](int st, int slot) {  // st, slot are compile-time after unrolling
           const int tap = st / ICB, c = st % ICB;
-          const int P = Pb + (tap / 3) * LW + (tap % 3);
-          fb[slot] = *reinterpret_cast<const v4i *>(ins + P * IC + 16 * ((2 * c + h) ^ chunk_swizzle<CP>(P)));
+          fb[slot] = *reinterpret_cast<const v4i *>(ins + (tap / 3) * lds_row + bb[tap % 3][c]);
 #pragma unroll
           for (int r = 0; r < OCB; ++r)
             fw[slot][r] = *reinterpret_cast<const v4i *>(w0s + ((r * 9 + tap) * ICB + c) * 1024 + lane16);
@@ -555,56 +804,83 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
         for (int st = 0; st < NS; ++st) {
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int r = 0; r < OCB; ++r)
-            acc0[r] = FUSED ? mfma_i8(fw[st % RD][r], fb[st % RD], acc0[r])   // D0[oc][px]
-                            : mfma_i8(fb[st % RD], fw[st % RD][r], acc0[r]);  // D0[px][oc]
+          for (int r = 0; r < OCB; ++r) {
+            if (FUSED) acc0[r] = mfma_i8(fw[st % RD][r], fb[st % RD], acc0[r]);        // D0[oc][px]
+            else if (st == 0) acc0[r] = mfma_i8_from_magic(fb[st % RD], fw[st % RD][r]);
+            else acc0[r] = mfma_i8(fb[st % RD], fw[st % RD][r], acc0[r]);              // D0[px][oc]
+          }
           __builtin_amdgcn_sched_barrier(0);
           if (st + RD - 1 < NS) fetch(st + RD - 1, (st + RD - 1) % RD);
         }
       }
 
+      DFX_TRACE_AT(61, 0, 0);
       unsigned char *tile_dst = reinterpret_cast<unsigned char *>(a.dst) + obase * row_bytes;
       using T = std::true_type;
       using F = std::false_type;
       if constexpr (!FUSED) {
         // ---- unfused: requant 0 + typed store straight from the 3x3 accumulators ----
         const int chb = lch;  // G == OCB: this lane owns channels G*l31 .. G*l31 + G-1
-        float cp[G], bs[G], sc[G];
+        int ia[G];
+        v2f fb[G], fc[G];
 #pragma unroll
         for (int cc = 0; cc < G; ++cc) {
-          cp[cc] = comp0[chb + cc];
-          bs[cc] = bias0[chb + cc];
-          sc[cc] = scale0[chb + cc];
+          ia[cc] = ia0[chb + cc];
+          fb[cc] = pb0[chb + cc];
+          fc[cc] = pc0[chb + cc];
         }
+        // Partial tiles (check_tag): the lanes beyond nvalid loaded the tile's LAST valid pixel
+        // (min(l31, nvalid - 1) above), so their rows of the result are copies of that pixel's row:
+        // they store the same bytes to that pixel's address -- no predicate, no divergent branch.
+        // All addresses are the wave-uniform tile_dst plus a 32-bit per-lane byte offset.
         const unsigned lane_off = (unsigned)h4 * row_bytes + (unsigned)chb * ESZ;
-        auto emit0 = [&](auto fast_tag, auto check_tag) {
+        const unsigned ch_off = (unsigned)chb * ESZ;
+        auto emit0 = [&](auto mode_tag, auto check_tag) {
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int pl = 8 * (e >> 2) + (e & 3);  // + 4h, folded into lane_off
-            if (!decltype(check_tag)::value || pl + 4 * h < nvalid) {
-              int v[G];
-#pragma unroll
-              for (int cc = 0; cc < G; ++cc) v[cc] = acc0[cc][e];
-              store_group<DST, G, decltype(fast_tag)::value>(
-                  (tile_dst + (size_t)((unsigned)pl * row_bytes)) + lane_off, v, cp, bs, sc, relu1, a.rm0);
-            }
+          for (int e = 0; e < 16; e += 2) {
+            const int pl = 8 * (e >> 2) + (e & 3);  // + 4h: pixel of register e; e + 1 is the next pixel
+            const unsigned o0 = decltype(check_tag)::value ? (unsigned)min(pl + h4, nvalid - 1) * row_bytes + ch_off
+                                                           : (unsigned)pl * row_bytes + lane_off;
+            const unsigned o1 = decltype(check_tag)::value ? (unsigned)min(pl + 1 + h4, nvalid - 1) * row_bytes + ch_off
+                                                           : (unsigned)(pl + 1) * row_bytes + lane_off;
+            emit_pair<DST, G, decltype(mode_tag)::value>(tile_dst + o0, tile_dst + o1, acc0, e, ia, fb, fc, relu1, a.rm0);
           }
         };
-        if (fast) { if (nvalid == 32) emit0(T{}, F{}); else emit0(T{}, T{}); }
-        else      { if (nvalid == 32) emit0(F{}, F{}); else emit0(F{}, T{}); }
+        using M0 = std::integral_constant<int, 0>;
+        using M1 = std::integral_constant<int, 1>;
+        using M2 = std::integral_constant<int, 2>;
+        if (mode0 == 2) { if (nvalid == 32) emit0(M2{}, F{}); else emit0(M2{}, T{}); }
+        else if (mode0 == 1) { if (nvalid == 32) emit0(M1{}, F{}); else emit0(M1{}, T{}); }
+        else { if (nvalid == 32) emit0(M0{}, F{}); else emit0(M0{}, T{}); }
       } else {
       DFX_STAMP(c3);
       DFX_ACC(1, c3 - c2);  // conv0 MFMA issue
       // ---- requant 0 in registers -> A fragments of the 1x1 ----
       v4i mid[OCB];
-      if (fast) {  // cb0 = comp0 + bias0 (exact, host-proven); ReLU + RNE + sat + pack in one op
+      if (mode0 == 2) {  // accumulator bits are the float 1.5 * 2^23 + acc + bias: subtract, scale, pack
+#pragma unroll
+        for (int r = 0; r < OCB; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const v4f sc = *reinterpret_cast<const v4f *>(fc0 + 32 * r + 8 * q + h4);
+            unsigned pk = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+              v2f x = {__int_as_float(acc0[r][4 * q + i]), __int_as_float(acc0[r][4 * q + i + 1])};
+              x = (x + v2f{-MAGIC0_F, -MAGIC0_F}) * v2f{sc[i], sc[i + 1]};
+              pk = __builtin_amdgcn_cvt_pk_u8_f32(x[0], i, pk);
+              pk = __builtin_amdgcn_cvt_pk_u8_f32(x[1], i + 1, pk);
+            }
+            mid[r][q] = (int)(pk ^ 0x80808080u);
+          }
+      } else if (mode0 == 1) {  // ReLU + RNE + saturation + pack in one op
 #pragma unroll
         for (int r = 0; r < OCB; ++r)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int ch = 32 * r + 8 * q + h4;
-            const v4f bs = *reinterpret_cast<const v4f *>(bias0 + ch);
-            const v4f sc = *reinterpret_cast<const v4f *>(scale0 + ch);
+            const v4f bs = *reinterpret_cast<const v4f *>(fb0 + ch);
+            const v4f sc = *reinterpret_cast<const v4f *>(fc0 + ch);
             unsigned pk = 0;
 #pragma unroll
             for (int i = 0; i < 4; i += 2) {
@@ -621,38 +897,33 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int ch = 32 * r + 8 * q + h4;
-            const v4f cp = *reinterpret_cast<const v4f *>(comp0 + ch);
-            const v4f bs = *reinterpret_cast<const v4f *>(bias0 + ch);
-            const v4f sc = *reinterpret_cast<const v4f *>(scale0 + ch);
+            const v4f bs = *reinterpret_cast<const v4f *>(fb0 + ch);
+            const v4f sc = *reinterpret_cast<const v4f *>(fc0 + ch);
             unsigned pk = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const float f = __fmul_rn(acc_to_f32(acc0[r][4 * q + i], cp[i], bs[i]), sc[i]);
+              const float f = __fmul_rn(__fadd_rn(__int2float_rn(acc0[r][4 * q + i]), bs[i]), sc[i]);
               pk |= sat_u8_bits(cvt_x86_rt(relu_x86(f), a.rm0)) << (8 * i);
             }
             mid[r][q] = (int)(pk ^ 0x80808080u);
           }
       }
+      DFX_TRACE_AT(62, mode0, mode1);
       DFX_STAMP(c4);
       DFX_ACC(2, c4 - c3);  // requant 0
       // ---- conv1 + requant 1 + store, G column blocks at a time ----
       for (int cg = 0; cg < NCG; ++cg) {
+        DFX_TRACE_AT(63, cg, NCG);
         const int chb = 32 * G * cg + lch;  // this lane's first channel in the group
         v16i acc1[G];
-        float cp[G], bs[G], sc[G];
+        int ia[G];
+        v2f fb[G], fc[G];
 #pragma unroll
         for (int cc = 0; cc < G; ++cc) {
-          acc1[cc] = zero16;
-          cp[cc] = comp1[chb + cc];
-          bs[cc] = bias1[chb + cc];
-          sc[cc] = scale1[chb + cc];
+          ia[cc] = ia1[chb + cc];
+          fb[cc] = pb1[chb + cc];
+          fc[cc] = pc1[chb + cc];
         }
-        // All W1 fragments of the group are fetched into DISTINCT registers before the
-        // MFMA chain starts, and the chain is fenced off from the loads: no register
-        // that an in-flight MFMA reads as A/B is the destination of a later LDS load.
-        // (With the fragments rotating through two register quads, back-to-back MFMAs
-        // followed by a reload of the second one's B operand produced rare wrong
-        // accumulators on the first launches of a process on gfx950.)
         v4i wf[OCB][G];
 #pragma unroll
         for (int r = 0; r < OCB; ++r)
@@ -664,38 +935,50 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
 #pragma unroll
         for (int r = 0; r < OCB; ++r)
 #pragma unroll
-          for (int cc = 0; cc < G; ++cc) acc1[cc] = mfma_i8(mid[r], wf[r][cc], acc1[cc]);
+          for (int cc = 0; cc < G; ++cc)
+            acc1[cc] = r == 0 ? mfma_i8_from_magic(mid[0], wf[0][cc]) : mfma_i8(mid[r], wf[r][cc], acc1[cc]);
         __builtin_amdgcn_sched_barrier(0);
+        DFX_TRACE_AT(64, cg, nvalid);
         // register e of the accumulator = pixel 8*(e>>2) + 4h + (e&3) of the tile
-        const unsigned lane_off = (unsigned)h4 * row_bytes + (unsigned)chb * ESZ;
-        auto emit = [&](auto fast_tag, auto check_tag) {
+        // (opaque per group: keeps hipcc from hoisting 16 per-pixel offsets -- of both variants -- out of
+        // the group loop and spilling them to scratch)
+        unsigned rb = row_bytes;
+        int nv1 = __builtin_amdgcn_readfirstlane(nvalid - 1);
+        asm volatile("" : "+s"(rb), "+s"(nv1));
+        const unsigned lane_off = (unsigned)h4 * rb + (unsigned)chb * ESZ;
+        const unsigned ch_off = (unsigned)chb * ESZ;
+        auto emit = [&](auto mode_tag, auto check_tag) {  // (partial tiles: see the unfused stage above)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int pl = 8 * (e >> 2) + (e & 3);  // + 4h, folded into lane_off
-            if (!decltype(check_tag)::value || pl + 4 * h < nvalid) {
-              int v[G];
-#pragma unroll
-              for (int cc = 0; cc < G; ++cc) v[cc] = acc1[cc][e];
-              store_group<DST, G, decltype(fast_tag)::value>(
-                  (tile_dst + (size_t)((unsigned)pl * row_bytes)) + lane_off, v, cp, bs, sc, relu1, a.rm1);
-            }
+          for (int e = 0; e < 16; e += 2) {
+            const int pl = 8 * (e >> 2) + (e & 3);  // + 4h: pixel of register e; e + 1 is the next pixel
+            const unsigned o0 = decltype(check_tag)::value ? (unsigned)min(pl + h4, nv1) * rb + ch_off
+                                                           : (unsigned)pl * rb + lane_off;
+            const unsigned o1 = decltype(check_tag)::value ? (unsigned)min(pl + 1 + h4, nv1) * rb + ch_off
+                                                           : (unsigned)(pl + 1) * rb + lane_off;
+            emit_pair<DST, G, decltype(mode_tag)::value>(tile_dst + o0, tile_dst + o1, acc1, e, ia, fb, fc, relu1, a.rm1);
           }
         };
-        if (fast) { if (nvalid == 32) emit(T{}, F{}); else emit(T{}, T{}); }
-        else      { if (nvalid == 32) emit(F{}, F{}); else emit(F{}, T{}); }
+        using M0 = std::integral_constant<int, 0>;
+        using M1 = std::integral_constant<int, 1>;
+        using M2 = std::integral_constant<int, 2>;
+        if (mode1 == 2) { if (nvalid == 32) emit(M2{}, F{}); else emit(M2{}, T{}); }
+        else if (mode1 == 1) { if (nvalid == 32) emit(M1{}, F{}); else emit(M1{}, T{}); }
+        else { if (nvalid == 32) emit(M0{}, F{}); else emit(M0{}, T{}); }
+        DFX_TRACE_AT(66, cg, 0);
       }
       DFX_STAMP(c5);
       DFX_ACC(3, c5 - c4);  // conv1 + requant 1 + stores
       }  // FUSED
       DFX_ACC(6, 1);
     }
+    DFX_TRACE_AT(7, t, 0);
     DFX_STAMP(c6);
-    // this wave is done with buffer b (its LDS reads have been consumed by the MFMAs)
-    // (one add per WAVE: lane 0 only)
-    if (lane == 0) __hip_atomic_fetch_add(done + b, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    DFX_ACC(5, c6 - c0);  // whole unit
+    // count this claim off on its slot (the tile's LDS reads have been consumed by the MFMAs)
+    __hip_atomic_fetch_add(ctrl + CTL_DONE + s, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // all 64 lanes: + 64
+    DFX_ACC(5, c6 - c0);  // whole claim
     DFX_ACC(7, 1);
   }
+  DFX_TRACE_AT(9, 0, 0);
 #ifdef DFX_STAMPS
   {
     DFX_STAMP(t_end);

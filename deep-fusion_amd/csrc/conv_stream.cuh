@@ -542,7 +542,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
                   const unsigned off = pxoff[32 * (wave * PXB + pb) + px];
                   const v4i val = *reinterpret_cast<const v4i *>(stg + px * RS + 16 * c16);
                   const int ch = 32 * OCC * occ + 16 * c16;
-                  if (off != 0xffffffffu && ch < a.oc) DFX_STORE(reinterpret_cast<v4i *>(dst_b + (size_t)(off + ch)), val);
+                  if (off != 0xffffffffu && ch < a.oc) DFX_STORE16(reinterpret_cast<v4i *>(dst_b + (size_t)(off + ch)), val);
                 }
               }
             };
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
                   const unsigned off = pxoff[32 * (wave * PXB + pb) + px];
                   const v4i val = *reinterpret_cast<const v4i *>(stg + px * 144 + 16 * c16);
                   if (off != 0xffffffffu && 128 * g1 + 16 * c16 < a.oc1)
-                    DFX_STORE(reinterpret_cast<v4i *>(dst_b + (size_t)(off + 128 * g1 + 16 * c16)), val);
+                    DFX_STORE16(reinterpret_cast<v4i *>(dst_b + (size_t)(off + 128 * g1 + 16 * c16)), val);
                 }
               }
             }

@@ -17,7 +17,10 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "conv_mfma.cuh"
@@ -83,7 +86,56 @@ static int fail(int code, const char *fmt, ...) {
 
 static size_t dt_size(int dt) { return (dt == DFX_F32 || dt == DFX_S32) ? 4 : 1; }
 
+// ---- testing / tuning switches.  The environment is read ONCE, when the
+//      library is first used; tests flip a switch afterwards with dfx_debug_set_tuning(). ----
+namespace {
+const char *const kTuningKeys[] = {"DFX_MAX_TH", "DFX_FORCE_GEOM", "DFX_STATIC_ROUNDS", "DFX_NO_FAST", "DFX_NO_MAGIC",
+                                   "DFX_STREAM_PXB", "DFX_STREAM_BLOCKING", "DFX_STREAM_PLANES", "DFX_STREAM_OCC_PAR",
+                                   "DFX_STREAM_SPLIT", "DFX_STREAM_DIRECT", "DFX_STREAM_GRID", "DFX_DEBUG_PTRS",
+                                   "DEEPFUSION_PROFILE"};
+struct Tuning {
+  std::mutex mu;
+  std::map<std::string, std::string> kv;
+  Tuning() {
+    for (const char *k : kTuningKeys)
+      if (const char *v = getenv(k)) kv[k] = v;
+  }
+};
+Tuning &tuning() {
+  static Tuning t;
+  return t;
+}
+// value of a switch or nullptr; the returned pointer stays valid until the switch is set again
+// (thread_local copy: callers use it immediately)
+const char *tune(const char *key) {
+  static thread_local std::string held;
+  Tuning &t = tuning();
+  std::lock_guard<std::mutex> lk(t.mu);
+  auto it = t.kv.find(key);
+  if (it == t.kv.end()) return nullptr;
+  held = it->second;
+  return held.c_str();
+}
+}  // namespace
+
+// launches of one MFMA-variant handle that may be in flight at the same time (any streams)
+constexpr unsigned DFX_QUEUE_RING = 16;
+
+// every entry point that takes a handle runs on the device the handle was created on
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (dev >= 0 && dev != prev) (void)hipSetDevice(dev);
+    else prev = -1;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
 struct dfx_conv {
+  int device;  // ordinal the handle lives on (current device at dfx_conv_create)
   dfx_conv_desc d;
   int variant;
   ConvArgs args;
@@ -98,7 +150,9 @@ struct dfx_conv {
   void *d_mid;
   int icb, ocb, G, grid, block, lds;
   void *d_wei, *d_wei1, *d_consts;
-  int *d_queue;  // MFMA variant: {next unit, finished workgroups}
+  int *d_queue;  // MFMA variant: ring of DFX_QUEUE_RING x {next unit, finished loaders}, one slot per launch in flight
+  unsigned launch_seq;
+  int *trace_host;  // DFX_TRACE builds only
   unsigned long long *d_prof;  // DFX_STAMPS builds only
   bool weights_set;
   void *d_src, *d_dst;  // lazily allocated for dfx_conv_submit_host
@@ -107,6 +161,7 @@ struct dfx_conv {
 };
 
 struct dfx_concat {
+  int device;
   dfx_concat_desc d;
   std::vector<int> channels;
   ConcatArgs args;
@@ -184,6 +239,35 @@ int dfx_stream_sync(dfx_stream_t s) {
   HIP_TRY(hipStreamSynchronize((hipStream_t)s));
   return DFX_OK;
 }
+int dfx_stream_wait_stream(dfx_stream_t waiter, dfx_stream_t producer) {
+  if (waiter == producer) return DFX_OK;
+  hipEvent_t e;
+  HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  hipError_t r = hipEventRecord(e, (hipStream_t)producer);
+  if (r == hipSuccess) r = hipStreamWaitEvent((hipStream_t)waiter, e, 0);
+  (void)hipEventDestroy(e);  // (released once the recorded work has completed)
+  HIP_TRY(r);
+  return DFX_OK;
+}
+int dfx_event_create(dfx_event_t *e) {
+  hipEvent_t ev;
+  HIP_TRY(hipEventCreate(&ev));
+  *e = ev;
+  return DFX_OK;
+}
+int dfx_event_record(dfx_event_t e, dfx_stream_t s) {
+  HIP_TRY(hipEventRecord((hipEvent_t)e, (hipStream_t)s));
+  return DFX_OK;
+}
+int dfx_event_elapsed_ms(dfx_event_t start, dfx_event_t stop, float *ms) {
+  HIP_TRY(hipEventSynchronize((hipEvent_t)stop));
+  HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return DFX_OK;
+}
+int dfx_event_destroy(dfx_event_t e) {
+  if (e) HIP_TRY(hipEventDestroy((hipEvent_t)e));
+  return DFX_OK;
+}
 
 size_t dfx_blocked_offset(int o, int i, int kh, int kw, int I, int KH, int KW) {
   // [o/16][i/16][kh][kw][(i%16)/4][o%16][i%4], jit_conv_kernel.cc:333-338
@@ -248,16 +332,16 @@ static size_t round16(size_t v) { return (v + 15) & ~(size_t)15; }
 static bool pick_geometry(const dfx_conv_desc &d, MfmaGeom &g, int &lds) {
   const int ICB = d.ic / 32, OCB = d.oc / 32, NCB = d.oc1x1 / 32;
   const size_t fixed = (size_t)OCB * 9 * ICB * 1024 + (size_t)NCB * OCB * 1024 +
-                       round16((size_t)3 * (d.oc + d.oc1x1) * 4) + MFMA_CTRL_BYTES;
+                       round16((size_t)mfma_cst_floats(d.oc, d.oc1x1) * 4) + MFMA_CTRL_BYTES;
   const size_t lds_max = 163840;  // one workgroup per CU owns the whole LDS
   if (fixed + 4 * 1024 > lds_max) return false;
-  const size_t tile_max = (lds_max - fixed) / (2 * MFMA_TEAMS);  // four tile buffers
+  const size_t tile_max = (lds_max - fixed) / MFMA_NB;  // ring of MFMA_NB tile slots
   // rows per unit wanted for parallelism: aim for >= ~3 units per team (512 teams)
   int th_par = (int)(((long long)d.bs * d.oh) / 1536);
   if (th_par < 1) th_par = 1;
   if (th_par < 2 && (long long)d.bs * d.oh / 2 >= 512) th_par = 2;
   if (th_par > 16) th_par = 16;
-  if (const char *e = getenv("DFX_MAX_TH")) th_par = std::max(1, std::min(th_par, atoi(e)));  // tuning aid
+  if (const char *e = tune("DFX_MAX_TH")) th_par = std::max(1, std::min(th_par, atoi(e)));  // tuning aid
   const bool hbm_bound_dst = d.dst_dt == DFX_S32 || d.dst_dt == DFX_F32;
   double best = -1.0;
   for (int mode = 0; mode < 2; ++mode)
@@ -275,14 +359,11 @@ static bool pick_geometry(const dfx_conv_desc &d, MfmaGeom &g, int &lds) {
                              ((double)((d.oh + th - 1) / th * th) * ((d.ow + tw - 1) / tw * tw));
         const bool oversize = (tile - 16) / 16 > (size_t)64 * MFMA_LC;
         double score = px_eff * cover * (0.75 + 0.25 * halo_eff) * (oversize ? 0.9 : 1.0);
-        // 4-byte outputs are HBM-write bound and the XCDs drain at different rates: the
-        // dynamic tail then dominates, so prefer >= ~7 units per team (finer hand-out)
-        // over perfectly filled waves (measured: 4 -> 2 rows per unit = -5 % at config 3)
-        if (hbm_bound_dst) {
-          const long long units = (long long)d.bs * ((d.oh + th - 1) / th) * ((d.ow + tw - 1) / tw);
-          if (th > 1 && units < 6LL * 2 * 256) score *= 0.5;
-          if (mode == 0) score *= 1.08;  // full-width units measured best here (2x56: 86 us, 4x32: 89 us, 4x56: 93 us)
-        }
+        // The 14 compute waves of a CU claim tiles from the units in the 4-slot LDS ring: a unit should
+        // bring >= 7 tiles so that two units in flight keep every wave busy while two more are staged
+        // (measured at config 3, s32: 2-row units of 4 tiles 124 us, 4-row units of 7 tiles 97 us)
+        score *= 0.5 + 0.5 * std::min(1.0, ntiles / 7.0);
+        (void)hbm_bound_dst;
         if (score > best) {
           best = score;
           g.th = th; g.tw = tw; g.linear = mode == 0;
@@ -290,7 +371,7 @@ static bool pick_geometry(const dfx_conv_desc &d, MfmaGeom &g, int &lds) {
       }
     }
   if (best < 0) return false;
-  if (const char *e = getenv("DFX_FORCE_GEOM")) {  // tuning aid: "th,tw" (must fit LDS)
+  if (const char *e = tune("DFX_FORCE_GEOM")) {  // tuning aid: "th,tw" (must fit LDS)
     int fth = 0, ftw = 0;
     if (sscanf(e, "%d,%d", &fth, &ftw) == 2 && fth >= 1 && (ftw == d.ow || (ftw % 32 == 0 && ftw < d.ow)) &&
         (size_t)(fth + 2) * (ftw + 2) * d.ic + 16 <= tile_max) {
@@ -304,11 +385,16 @@ static bool pick_geometry(const dfx_conv_desc &d, MfmaGeom &g, int &lds) {
   g.tile_chunks = (g.th + 2) * g.row_chunks;
   g.row_magic = (unsigned)(((1ull << 32) + g.row_chunks - 1) / g.row_chunks);
   g.tile_stride = g.tile_chunks * 16 + 16;
-  lds = (int)(fixed + (size_t)2 * MFMA_TEAMS * g.tile_stride);
+  g.tw_magic = (unsigned)(((1ull << 32) + g.tw - 1) / g.tw);
+  g.ntu = g.linear ? (g.th * g.tw + 31) / 32 : g.th * (g.tw / 32);  // tile claims per unit
+  g.ntu_magic = (unsigned)(((1ull << 32) + g.ntu - 1) / g.ntu);
+  g.claim_limit = (int)std::min<long long>(0x7ffffff0LL, (long long)g.ntu * ((long long)g.total_units + 4));
+  lds = (int)(fixed + (size_t)MFMA_NB * g.tile_stride);
   return true;
 }
 
 static bool mfma_eligible(const dfx_conv_desc &d) {  // fused or unfused (oc1x1 == 0)
+  if ((long long)d.bs * d.oh * d.ow >= (1LL << 31) - 64) return false;  // (pixel indices are 32-bit in the kernel)
   return d.kh == 3 && d.kw == 3 && d.sh == 1 && d.sw == 1 && d.pad_t <= 1 && d.pad_l <= 1 &&
          (d.ic == 32 || d.ic == 64) && (d.oc == 32 || d.oc == 64) && d.oc1x1 % 32 == 0;
 }
@@ -366,12 +452,12 @@ static bool pick_direct_geometry(const dfx_conv_desc &d, int WO, int G, DirectGe
   return true;
 }
 
-static int direct_dispatch(dfx_conv *h, hipStream_t s, int mode) {
+static int direct_dispatch(dfx_conv *h, const ConvArgs &a, hipStream_t s, int mode) {
   switch (h->d.dst_dt) {
-    case DFX_F32: return launch_conv_direct_f32(h->args, h->dgeom, h->wo, h->G, h->wo1, h->grid, h->lds, s, mode);
-    case DFX_S32: return launch_conv_direct_s32(h->args, h->dgeom, h->wo, h->G, h->wo1, h->grid, h->lds, s, mode);
-    case DFX_S8: return launch_conv_direct_s8(h->args, h->dgeom, h->wo, h->G, h->wo1, h->grid, h->lds, s, mode);
-    case DFX_U8: return launch_conv_direct_u8(h->args, h->dgeom, h->wo, h->G, h->wo1, h->grid, h->lds, s, mode);
+    case DFX_F32: return launch_conv_direct_f32(a, h->dgeom, h->wo, h->G, h->wo1, h->grid, h->lds, s, mode);
+    case DFX_S32: return launch_conv_direct_s32(a, h->dgeom, h->wo, h->G, h->wo1, h->grid, h->lds, s, mode);
+    case DFX_S8: return launch_conv_direct_s8(a, h->dgeom, h->wo, h->G, h->wo1, h->grid, h->lds, s, mode);
+    case DFX_U8: return launch_conv_direct_u8(a, h->dgeom, h->wo, h->G, h->wo1, h->grid, h->lds, s, mode);
   }
   return -1;
 }
@@ -448,7 +534,7 @@ static bool pick_stream_geometry(const dfx_conv_desc &d, int OCC, int G, int PXB
   if (g.n_icc > 1 && (restaged || short_chunks) &&
       fixed + std::max((size_t)g.n_icc * g.npos * ST_POS + 16, stage_bytes) <= 81920)
     g.planes = g.n_icc;
-  if (const char *e = getenv("DFX_STREAM_PLANES"))  // testing aid: 0 = never, 1 = whenever it fits LDS at all
+  if (const char *e = tune("DFX_STREAM_PLANES"))  // testing aid: 0 = never, 1 = whenever it fits LDS at all
     g.planes = (atoi(e) && g.n_icc > 1 && fixed + std::max((size_t)g.n_icc * g.npos * ST_POS + 16, stage_bytes) <= lds_max) ? g.n_icc : 1;
   {
     auto magic = [](long long x) { return (unsigned)(((1ull << 32) + (unsigned long long)x - 1) / (unsigned long long)x); };
@@ -463,33 +549,35 @@ static bool pick_stream_geometry(const dfx_conv_desc &d, int OCC, int G, int PXB
   return true;
 }
 
-static int stream_dispatch(dfx_conv *h, hipStream_t s, int mode) {
+static int stream_dispatch(dfx_conv *h, const ConvArgs &a, hipStream_t s, int mode) {
   const int fused = h->d.oc1x1 > 0;
   switch (h->d.dst_dt) {
-    case DFX_F32: return launch_conv_stream_f32(h->args, h->sgeom, h->occ, h->G, h->pxb, fused, h->grid, h->lds, s, mode);
-    case DFX_S32: return launch_conv_stream_s32(h->args, h->sgeom, h->occ, h->G, h->pxb, fused, h->grid, h->lds, s, mode);
-    case DFX_S8: return launch_conv_stream_s8(h->args, h->sgeom, h->occ, h->G, h->pxb, fused, h->grid, h->lds, s, mode);
-    case DFX_U8: return launch_conv_stream_u8(h->args, h->sgeom, h->occ, h->G, h->pxb, fused, h->grid, h->lds, s, mode);
+    case DFX_F32: return launch_conv_stream_f32(a, h->sgeom, h->occ, h->G, h->pxb, fused, h->grid, h->lds, s, mode);
+    case DFX_S32: return launch_conv_stream_s32(a, h->sgeom, h->occ, h->G, h->pxb, fused, h->grid, h->lds, s, mode);
+    case DFX_S8: return launch_conv_stream_s8(a, h->sgeom, h->occ, h->G, h->pxb, fused, h->grid, h->lds, s, mode);
+    case DFX_U8: return launch_conv_stream_u8(a, h->sgeom, h->occ, h->G, h->pxb, fused, h->grid, h->lds, s, mode);
   }
   return -1;
 }
 
-static int mfma_dispatch(dfx_conv *h, hipStream_t s, int mode) {
-  if (h->variant == DFX_VARIANT_MFMA_STREAM) return h->direct ? direct_dispatch(h, s, mode) : stream_dispatch(h, s, mode);
+// `a` and `g` are per-launch copies (src/dst pointers, queue slot): submits of one handle do not
+// share mutable host state
+static int mfma_dispatch(dfx_conv *h, const ConvArgs &a, const MfmaGeom &g, hipStream_t s, int mode) {
+  if (h->variant == DFX_VARIANT_MFMA_STREAM) return h->direct ? direct_dispatch(h, a, s, mode) : stream_dispatch(h, a, s, mode);
   if (h->variant == DFX_VARIANT_MFMA_CONV) {
     switch (h->d.dst_dt) {
-      case DFX_F32: return launch_conv_mfma_f32_unfused(h->args, h->geom, h->icb, h->ocb, h->grid, h->lds, s, mode);
-      case DFX_S32: return launch_conv_mfma_s32_unfused(h->args, h->geom, h->icb, h->ocb, h->grid, h->lds, s, mode);
-      case DFX_S8: return launch_conv_mfma_s8_unfused(h->args, h->geom, h->icb, h->ocb, h->grid, h->lds, s, mode);
-      case DFX_U8: return launch_conv_mfma_u8_unfused(h->args, h->geom, h->icb, h->ocb, h->grid, h->lds, s, mode);
+      case DFX_F32: return launch_conv_mfma_f32_unfused(a, g, h->icb, h->ocb, h->grid, h->lds, s, mode);
+      case DFX_S32: return launch_conv_mfma_s32_unfused(a, g, h->icb, h->ocb, h->grid, h->lds, s, mode);
+      case DFX_S8: return launch_conv_mfma_s8_unfused(a, g, h->icb, h->ocb, h->grid, h->lds, s, mode);
+      case DFX_U8: return launch_conv_mfma_u8_unfused(a, g, h->icb, h->ocb, h->grid, h->lds, s, mode);
     }
     return -1;
   }
   switch (h->d.dst_dt) {
-    case DFX_F32: return launch_conv_mfma_f32(h->args, h->geom, h->icb, h->ocb, h->G, h->grid, h->lds, s, mode);
-    case DFX_S32: return launch_conv_mfma_s32(h->args, h->geom, h->icb, h->ocb, h->G, h->grid, h->lds, s, mode);
-    case DFX_S8: return launch_conv_mfma_s8(h->args, h->geom, h->icb, h->ocb, h->G, h->grid, h->lds, s, mode);
-    case DFX_U8: return launch_conv_mfma_u8(h->args, h->geom, h->icb, h->ocb, h->G, h->grid, h->lds, s, mode);
+    case DFX_F32: return launch_conv_mfma_f32(a, g, h->icb, h->ocb, h->G, h->grid, h->lds, s, mode);
+    case DFX_S32: return launch_conv_mfma_s32(a, g, h->icb, h->ocb, h->G, h->grid, h->lds, s, mode);
+    case DFX_S8: return launch_conv_mfma_s8(a, g, h->icb, h->ocb, h->G, h->grid, h->lds, s, mode);
+    case DFX_U8: return launch_conv_mfma_u8(a, g, h->icb, h->ocb, h->G, h->grid, h->lds, s, mode);
   }
   return -1;
 }
@@ -497,6 +585,7 @@ static int mfma_dispatch(dfx_conv *h, hipStream_t s, int mode) {
 // releases everything a conv handle owns (also used on dfx_conv_create's failure paths)
 static void conv_release(dfx_conv *h) {
   if (!h) return;
+  DeviceGuard dg(h->device);
   if (h->host_stream) (void)hipStreamDestroy(h->host_stream);
   (void)hipFree(h->d_wei); (void)hipFree(h->d_wei1); (void)hipFree(h->d_consts);
   (void)hipFree(h->d_src); (void)hipFree(h->d_dst); (void)hipFree(h->d_queue);
@@ -522,6 +611,7 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
   if (!h) return fail(DFX_ERR_HIP, "out of host memory");
   memset(static_cast<void *>(h), 0, sizeof(*h));
   h->d = *desc;
+  if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
   const dfx_conv_desc &d = h->d;
 
   ConvArgs &a = h->args;
@@ -541,7 +631,7 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
   if (want_stream) {
     h->occ = pick_blocking((d.oc + 31) / 32);
     h->G = d.oc1x1 ? pick_blocking((d.oc1x1 + 31) / 32) : h->occ;
-    if (const char *e = getenv("DFX_STREAM_BLOCKING")) {  // tuning aid: "occ,g" from {1,2,4}
+    if (const char *e = tune("DFX_STREAM_BLOCKING")) {  // tuning aid: "occ,g" from {1,2,4}
       int o = 0, gg = 0;
       if (sscanf(e, "%d,%d", &o, &gg) == 2 && (o == 1 || o == 2 || o == 4) && (gg == 1 || gg == 2 || gg == 4)) {
         h->occ = o;
@@ -557,9 +647,9 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
       if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
     }
     h->pxb = 2;
-    if (const char *e = getenv("DFX_STREAM_PXB")) h->pxb = atoi(e) == 1 ? 1 : 2;  // tuning aid
+    if (const char *e = tune("DFX_STREAM_PXB")) h->pxb = atoi(e) == 1 ? 1 : 2;  // tuning aid
     stream_ok = h->pxb == 2 && pick_stream_geometry(d, h->occ, h->G, 2, false, h->sgeom, h->lds) &&
-                ((h->sgeom.total_units >= 4 * ncu && h->lds <= 81920) || getenv("DFX_STREAM_PXB"));
+                ((h->sgeom.total_units >= 4 * ncu && h->lds <= 81920) || tune("DFX_STREAM_PXB"));
     if (!stream_ok) {
       h->pxb = 1;
       stream_ok = pick_stream_geometry(d, h->occ, h->G, 1, false, h->sgeom, h->lds);
@@ -577,7 +667,7 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
   // DFX_STREAM_DIRECT=1/0 forces it on (wherever it fits) / off.
   bool want_direct = stream_ok && d.oc1x1 > 0 && d.oc >= 64 && d.oc1x1 >= 64 && d.ic >= 256 &&
                      4 * h->sgeom.total_units > 2 * 256;
-  if (const char *e = getenv("DFX_STREAM_DIRECT")) want_direct = stream_ok && d.oc1x1 > 0 && d.oc >= 64 && d.oc1x1 >= 64 && atoi(e) != 0;
+  if (const char *e = tune("DFX_STREAM_DIRECT")) want_direct = stream_ok && d.oc1x1 > 0 && d.oc >= 64 && d.oc1x1 >= 64 && atoi(e) != 0;
   if (want_direct) {
     const int ocb2 = ((d.oc + 31) / 32 + 1) / 2 * 2;
     h->wo = ocb2 % 4 == 0 ? 4 : 2;
@@ -600,14 +690,14 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
       conv_release(h);
       return fail(DFX_ERR_HIP, "conv_create: cannot query the device");
     }
-    if (mfma_dispatch(h, nullptr, 1) != 0) {
+    if (mfma_dispatch(h, h->args, h->geom, nullptr, 1) != 0) {
       conv_release(h);
       return fail(DFX_ERR_HIP, "conv_create: cannot raise dynamic LDS limit to %d bytes", h->lds);
     }
-    int per_cu = mfma_dispatch(h, nullptr, 2);
+    int per_cu = mfma_dispatch(h, h->args, h->geom, nullptr, 2);
     if (per_cu < 1) per_cu = 1;
     h->grid = std::min(h->dgeom.total_units, prop.multiProcessorCount * per_cu);
-    if (const char *e = getenv("DFX_STREAM_GRID")) h->grid = std::max(1, std::min(h->grid, atoi(e)));  // testing aid
+    if (const char *e = tune("DFX_STREAM_GRID")) h->grid = std::max(1, std::min(h->grid, atoi(e)));  // testing aid
     a.rows_per_unit = h->dgeom.thv;
     a.units_per_image = h->dgeom.uy * h->dgeom.ux;
     snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_direct_kernel<%d,%d,%d,%d>", h->wo, h->G, h->wo1, d.dst_dt);
@@ -636,20 +726,20 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
       conv_release(h);
       return fail(DFX_ERR_HIP, "conv_create: cannot query the device");
     }
-    if (mfma_dispatch(h, nullptr, 1) != 0) {
+    if (mfma_dispatch(h, h->args, h->geom, nullptr, 1) != 0) {
       conv_release(h);
       return fail(DFX_ERR_HIP, "conv_create: cannot raise dynamic LDS limit to %d bytes", h->lds);
     }
-    int per_cu = mfma_dispatch(h, nullptr, 2);
+    int per_cu = mfma_dispatch(h, h->args, h->geom, nullptr, 2);
     if (per_cu < 1) per_cu = 1;
     const int capacity = prop.multiProcessorCount * per_cu;  // resident workgroups
     // unfused op whose units leave workgroup slots empty: hand out (unit, output chunk) items
     h->sgeom.occ_par = (d.oc1x1 == 0 && h->sgeom.n_occ > 1 && h->sgeom.total_units < 2 * capacity) ? 1 : 0;
-    if (const char *e = getenv("DFX_STREAM_OCC_PAR")) h->sgeom.occ_par = (d.oc1x1 == 0 && h->sgeom.n_occ > 1 && atoi(e)) ? 1 : 0;  // testing aid
+    if (const char *e = tune("DFX_STREAM_OCC_PAR")) h->sgeom.occ_par = (d.oc1x1 == 0 && h->sgeom.n_occ > 1 && atoi(e)) ? 1 : 0;  // testing aid
     if (h->sgeom.occ_par) {  // lay LDS out again for one output chunk per item (same units)
       const int units = h->sgeom.total_units;
       if (!pick_stream_geometry(d, h->occ, h->G, h->pxb, true, h->sgeom, h->lds) || h->sgeom.total_units != units ||
-          mfma_dispatch(h, nullptr, 1) != 0) {
+          mfma_dispatch(h, h->args, h->geom, nullptr, 1) != 0) {
         conv_release(h);
         return fail(DFX_ERR_HIP, "conv_create: internal: chunk-parallel layout failed");
       }
@@ -661,7 +751,7 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     // below a quarter of the machine)
     bool split = d.oc1x1 > 0 && 4 * h->sgeom.total_units <= capacity &&
                  ((d.oc + 127) / 128 > 1 || (d.oc1x1 + 127) / 128 > 1);
-    if (const char *e = getenv("DFX_STREAM_SPLIT")) split = d.oc1x1 > 0 && atoi(e) != 0;  // testing aid
+    if (const char *e = tune("DFX_STREAM_SPLIT")) split = d.oc1x1 > 0 && atoi(e) != 0;  // testing aid
     if (split) {
       dfx_conv_desc d0 = d, d1 = d;
       d0.oc1x1 = 0; d0.dst_dt = DFX_U8; d0.bia1_dt = DFX_UNDEF; d0.conv1_nscales = 1;
@@ -677,7 +767,7 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
         h->split0 = h->split1 = nullptr; h->d_mid = nullptr;  // fall back to the single fused launch
       }
     }
-    if (const char *e = getenv("DFX_STREAM_GRID")) h->grid = std::max(1, std::min(h->grid, atoi(e)));  // testing aid
+    if (const char *e = tune("DFX_STREAM_GRID")) h->grid = std::max(1, std::min(h->grid, atoi(e)));  // testing aid
 #ifdef DFX_STAMPS
     if (hipMalloc((void **)&h->d_prof, (size_t)h->grid * 96 * 8) != hipSuccess ||
         hipMemset(h->d_prof, 0, (size_t)h->grid * 96 * 8) != hipSuccess) {
@@ -712,17 +802,17 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
       if (h->grid > want) h->grid = want;
     }
     h->block = MFMA_THREADS;
-    if (hipMalloc((void **)&h->d_queue, 16) != hipSuccess ||
-        hipMemset(h->d_queue, 0, 16) != hipSuccess) {
+    if (hipMalloc((void **)&h->d_queue, 8 * DFX_QUEUE_RING) != hipSuccess ||
+        hipMemset(h->d_queue, 0, 8 * DFX_QUEUE_RING) != hipSuccess) {
       conv_release(h);
       return fail(DFX_ERR_HIP, "conv_create: cannot allocate the unit queue");
     }
     h->geom.queue = h->d_queue;
-    h->geom.fast = 0;
+    h->geom.mode0 = h->geom.mode1 = 0;
     {
       const int teams = h->grid * MFMA_TEAMS;
       h->geom.static_rounds = std::min(3, std::max(0, h->geom.total_units / teams - 1));
-      if (const char *e = getenv("DFX_STATIC_ROUNDS")) h->geom.static_rounds = std::min(std::max(0, h->geom.total_units / teams - 1), atoi(e));  // tuning aid
+      if (const char *e = tune("DFX_STATIC_ROUNDS")) h->geom.static_rounds = std::min(std::max(0, h->geom.total_units / teams - 1), atoi(e));  // tuning aid
     }
 #ifdef DFX_STAMPS
     if (hipMalloc((void **)&h->d_prof, (size_t)h->grid * 256 * 8) != hipSuccess ||
@@ -732,11 +822,24 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     }
     h->geom.prof = h->d_prof;
 #endif
+#ifdef DFX_TRACE
+    {
+      void *hp = nullptr, *dp = nullptr;
+      if (hipHostMalloc(&hp, (size_t)h->grid * 16 * 4 * 4, hipHostMallocMapped) != hipSuccess ||
+          hipHostGetDevicePointer(&dp, hp, 0) != hipSuccess) {
+        conv_release(h);
+        return fail(DFX_ERR_HIP, "conv_create: cannot allocate the trace buffer");
+      }
+      memset(hp, 0, (size_t)h->grid * 16 * 4 * 4);
+      h->trace_host = (int *)hp;
+      h->geom.trace = (int *)dp;
+    }
+#endif
     a.rows_per_unit = h->geom.th;
     a.units_per_image = h->geom.uy * h->geom.ux;
     snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_mfma_fused_kernel<%d,%d,%d,%d%s>", h->icb,
              h->ocb, h->G, d.dst_dt, fused ? "" : ",unfused");
-    if (mfma_dispatch(h, nullptr, 1) != 0) {
+    if (mfma_dispatch(h, h->args, h->geom, nullptr, 1) != 0) {
       conv_release(h);
       return fail(DFX_ERR_HIP, "conv_create: cannot raise dynamic LDS limit to %d bytes", h->lds);
     }
@@ -858,7 +961,7 @@ static int set_weights_stream(dfx_conv_t *h, const int8_t *wei, const void *bia0
     put_f((size_t)3 * OCP + 2 * OC1P + c, sc);
     fast = fast && fast_ok_channel(255.0 * std::max(pos, -neg), 128.0 * sum, fb1[c], sc);
   }
-  if (const char *e = getenv("DFX_NO_FAST")) fast = fast && atoi(e) == 0;  // testing aid: force the exact path
+  if (const char *e = tune("DFX_NO_FAST")) fast = fast && atoi(e) == 0;  // testing aid: force the exact path
   if (fast) {  // the fast path reads comp + bias (an exact f32) from the bias slot
     for (int c = 0; c < OC; ++c) put_f((size_t)OCP + c, (float)((double)cst[c] + (double)fb0[c]));
     for (int c = 0; c < OC1; ++c)
@@ -940,7 +1043,7 @@ static int set_weights_direct(dfx_conv_t *h, const int8_t *wei, const void *bia0
     put_f((size_t)3 * OCP + 2 * OC1P + c, sc);
     fast = fast && fast_ok_channel(255.0 * std::max(pos, -neg), 128.0 * sum, fb1[c], sc);
   }
-  if (const char *e = getenv("DFX_NO_FAST")) fast = fast && atoi(e) == 0;  // testing aid: force the exact path
+  if (const char *e = tune("DFX_NO_FAST")) fast = fast && atoi(e) == 0;  // testing aid: force the exact path
   if (fast) {  // the fast path reads comp + bias (an exact f32) from the bias slot
     for (int c = 0; c < OC; ++c) put_f((size_t)OCP + c, (float)((double)cst[c] + (double)fb0[c]));
     for (int c = 0; c < OC1; ++c)
@@ -958,13 +1061,14 @@ static int set_weights_direct(dfx_conv_t *h, const int8_t *wei, const void *bia0
   h->args.wei1 = (const int8_t *)(base + n0);
   h->args.consts = (const float *)(base + pk.size());
   h->weights_set = true;
-  if (getenv("DFX_DEBUG_PTRS")) fprintf(stderr, "[dfx] direct weights %p..%p (W0 %zu, W1 %zu, consts %zu bytes)\n", (void *)base, (void *)(base + pk.size() + cst.size() * 4), n0, n1, cst.size() * 4);
+  if (tune("DFX_DEBUG_PTRS")) fprintf(stderr, "[dfx] direct weights %p..%p (W0 %zu, W1 %zu, consts %zu bytes)\n", (void *)base, (void *)(base + pk.size() + cst.size() * 4), n0, n1, cst.size() * 4);
   return DFX_OK;
 }
 
 int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei, const void *bia0, const float *scales0,
                          const int8_t *wei1, const void *bia1, const float *scales1) {
   if (!h || !wei || !scales0) return fail(DFX_ERR_INVALID, "set_weights: null argument");
+  DeviceGuard dg(h->device);
   const dfx_conv_desc &d = h->d;
   const bool fused = d.oc1x1 > 0;
   if (fused && (!wei1 || !scales1)) return fail(DFX_ERR_INVALID, "set_weights: fused op needs wei1x1 and scales1");
@@ -1024,60 +1128,124 @@ int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei, const void *bia0, con
             p1[(((size_t)cb * OCB + r) * 64 + lane) * 16 + j] =
                 wei1[dfx_blocked_offset(oc1, oc, 0, 0, OC, 1, 1)];
           }
-    // u8 -> s8 offset compensation: 128 * sum of the channel's weights
+    // ---- constants and requant mode per stage (conv_mfma.cuh header; emit_group) ----
+    // Per channel, from the ACTUAL weights: P = sum of positive weights, N = -sum of negative
+    // ones.  With activations stored as u8 - 128 in [-128, 127] the raw MFMA accumulator lies in
+    // [-(128 P + 127 N), 127 P + 128 N]; comp = 128 * (P - N) turns it into the reference's s32
+    // accumulator, |true acc| <= 255 * max(P, N).
+    struct Ch { double P, N; };
+    std::vector<Ch> c0(OC), c1(OC1 ? OC1 : 1);
     for (int oc = 0; oc < OC; ++oc) {
-      int32_t s = 0;
-      for (int ic = 0; ic < IC; ++ic)
-        for (int tap = 0; tap < 9; ++tap) s += wei[dfx_blocked_offset(oc, ic, tap / 3, tap % 3, IC, 3, 3)];
-      comp0[oc] = (float)(128 * s);
-    }
-    for (int o1 = 0; o1 < OC1; ++o1) {
-      int32_t s = 0;
-      for (int oc = 0; oc < OC; ++oc) s += wei1[dfx_blocked_offset(o1, oc, 0, 0, OC, 1, 1)];
-      comp1[o1] = (float)(128 * s);
-    }
-    // Fast requant path (conv_mfma.cuh, store_group<FAST>): both stages round to
-    // nearest-even; from the weights themselves no value can be NaN or reach +-2^31
-    // before vcvtps2dq (|acc| <= 255 * max(sum w+, -sum w-)); and comp + bias folds into
-    // ONE exact f32 add: bias integer-valued, |comp + bias| < 2^24 and |acc + bias| < 2^24,
-    // so float(acc) + float(bias) of the reference == float(raw) + float(comp + bias).
-    bool fast = d.conv0_round_mode == DFX_ROUND_NEAREST && (!fused || d.conv1_round_mode == DFX_ROUND_NEAREST);
-    auto ok_channel = [](double amax, float comp, float bias, float scale) {
-      if (!std::isfinite(bias) || !std::isfinite(scale)) return false;
-      const double b = bias;
-      if (b != std::floor(b)) return false;                       // integer-valued bias only
-      const double lim = 16777216.0;                              // 2^24
-      if (std::fabs((double)comp + b) >= lim || amax + std::fabs(b) >= lim) return false;
-      return (amax + std::fabs(b)) * std::fabs((double)scale) * 1.0001 + 2.0 < 2147480000.0;
-    };
-    for (int oc = 0; oc < OC && fast; ++oc) {
-      double pos = 0, neg = 0;
+      double P = 0, N = 0;
       for (int ic = 0; ic < IC; ++ic)
         for (int tap = 0; tap < 9; ++tap) {
           const int w = wei[dfx_blocked_offset(oc, ic, tap / 3, tap % 3, IC, 3, 3)];
-          (w > 0 ? pos : neg) += w;
+          (w > 0 ? P : N) += std::abs(w);
         }
-      fast = ok_channel(255.0 * std::max(pos, -neg), comp0[oc], b0[oc], s0[oc]);
+      c0[oc] = {P, N};
     }
-    for (int o1 = 0; o1 < OC1 && fast; ++o1) {
-      double pos = 0, neg = 0;
+    for (int o1 = 0; o1 < OC1; ++o1) {
+      double P = 0, N = 0;
       for (int oc = 0; oc < OC; ++oc) {
         const int w = wei1[dfx_blocked_offset(o1, oc, 0, 0, OC, 1, 1)];
-        (w > 0 ? pos : neg) += w;
+        (w > 0 ? P : N) += std::abs(w);
       }
-      fast = ok_channel(255.0 * std::max(pos, -neg), comp1[o1], b1[o1], s1[o1]);
+      c1[o1] = {P, N};
     }
-    if (fast) {  // the fast path reads comp + bias from the bias slot
-      for (int oc = 0; oc < OC; ++oc) b0[oc] = comp0[oc] + b0[oc];
-      for (int o1 = 0; o1 < OC1; ++o1) b1[o1] = comp1[o1] + b1[o1];
+    // "fast": rounding to nearest-even (the caller checks the round mode), every value finite and
+    // |f| < 2^31 so the x86 overflow / NaN results of vcvtps2dq cannot occur
+    auto fast_ok = [](const Ch &c, float bias, float scale) {
+      if (!std::isfinite(bias) || !std::isfinite(scale)) return false;
+      const double amax = 255.0 * std::max(c.P, c.N);
+      return (amax + std::fabs((double)bias)) * std::fabs((double)scale) * 1.0001 + 2.0 < 2147480000.0;
+    };
+    // "magic", accumulator started from bits(1.5 * 2^23) + comp + bias (stage 0 of a fused op):
+    // bias integer-valued and raw + comp + bias inside the binade, i.e. |.| < 2^22
+    auto magic0_ok = [](const Ch &c, float bias) {
+      const double b = bias, cb = 128.0 * (c.P - c.N) + b;
+      if (b != std::floor(b)) return false;
+      return -(128.0 * c.P + 127.0 * c.N) + cb > -4194304.0 && 127.0 * c.P + 128.0 * c.N + cb < 4194304.0;
+    };
+    // "magic", accumulator started from the inline constant 1/(2 pi) = 0x3E22F983 (ulp 2^-26):
+    // raw within the mantissa's room; k = (comp + bias - 2^23 - 0x22F983) exactly representable;
+    // |acc + bias| < 2^24; scale * 2^26 finite
+    auto magic1_ok = [](const Ch &c, float bias, float scale) {
+      const double b = bias, cb = 128.0 * (c.P - c.N) + b;
+      if (b != std::floor(b)) return false;
+      const double lo = -(128.0 * c.P + 127.0 * c.N), hi = 127.0 * c.P + 128.0 * c.N;
+      if (lo < (double)MAGIC1_LO || hi > (double)MAGIC1_HI) return false;
+      if (std::fabs(cb - 8388608.0 - (double)0x22F983) >= 16777216.0) return false;
+      if (std::fabs(lo + cb) >= 16777216.0 || std::fabs(hi + cb) >= 16777216.0) return false;
+      return std::isfinite(scale * 67108864.0f);
+    };
+    const bool no_fast = tune("DFX_NO_FAST") && atoi(tune("DFX_NO_FAST")) != 0;     // testing aid: exact paths
+    const bool no_magic = tune("DFX_NO_MAGIC") && atoi(tune("DFX_NO_MAGIC")) != 0;  // testing aid: no magic paths
+    int mode0 = (d.conv0_round_mode == DFX_ROUND_NEAREST && !no_fast) ? 2 : 0;
+    for (int oc = 0; oc < OC && mode0; ++oc) {
+      if (!fast_ok(c0[oc], b0[oc], s0[oc])) mode0 = 0;
+      else if (mode0 == 2 && !(fused ? magic0_ok(c0[oc], b0[oc]) : magic1_ok(c0[oc], b0[oc], s0[oc]))) mode0 = 1;
     }
-    h->geom.fast = fast ? 1 : 0;
+    int mode1 = (fused && d.conv1_round_mode == DFX_ROUND_NEAREST && !no_fast) ? 2 : 0;
+    for (int o1 = 0; o1 < OC1 && mode1; ++o1) {
+      if (!fast_ok(c1[o1], b1[o1], s1[o1])) mode1 = 0;
+      else if (mode1 == 2 && !magic1_ok(c1[o1], b1[o1], s1[o1])) mode1 = 1;
+    }
+    if (no_magic) { mode0 = std::min(mode0, 1); mode1 = std::min(mode1, 1); }
+    // slot A is an integer (bit copy into the f32 array), B and C are floats
+    auto put_i = [](float *dst, int32_t v) { memcpy(dst, &v, 4); };
+    auto inline_stage = [&](int mode, const Ch &c, float bias, float scale, float *A, float *B, float *C) {
+      const int32_t comp = (int32_t)(128.0 * (c.P - c.N));
+      put_i(A, comp - MAGIC1_BITS);  // acc bits + A = the reference's s32 accumulator
+      if (mode == 2) {
+        *B = (float)((double)comp + (double)bias - 8388608.0 - (double)0x22F983) * 1.4901161193847656e-08f;  // * 2^-26, exact
+        *C = scale * 67108864.0f;                                                                           // * 2^26, exact
+      } else {
+        *B = bias;
+        *C = scale;
+      }
+    };
+    for (int oc = 0; oc < OC; ++oc) {
+      if (fused) {
+        const int32_t comp = (int32_t)(128.0 * (c0[oc].P - c0[oc].N));
+        put_i(comp0 + oc, mode0 == 2 ? MAGIC0_BITS + comp + (int32_t)b0[oc] : comp);  // accumulator start value
+      } else {
+        float A, B, C;
+        inline_stage(mode0, c0[oc], b0[oc], s0[oc], &A, &B, &C);
+        comp0[oc] = A; b0[oc] = B; s0[oc] = C;
+      }
+    }
+    for (int o1 = 0; o1 < OC1; ++o1) {
+      float A, B, C;
+      inline_stage(mode1, c1[o1], b1[o1], s1[o1], &A, &B, &C);
+      comp1[o1] = A; b1[o1] = B; s1[o1] = C;
+    }
+    h->geom.mode0 = mode0;
+    h->geom.mode1 = mode1;
   } else {
     memcpy(p0.data(), wei, nw0);
     if (fused) memcpy(p1.data(), wei1, nw1);
   }
 
   if (h->variant != DFX_VARIANT_GENERIC) {
+    // constants in the kernel's layout: the storing stage's B and C as pairs {k, k} (conv_mfma.cuh,
+    // mfma_cst_floats)
+    {
+      std::vector<float> lay((size_t)mfma_cst_floats(OC, OC1), 0.0f);
+      if (fused) {
+        memcpy(lay.data(), cst.data(), (size_t)(3 * OC + OC1) * 4);  // A0 B0 C0 A1
+        for (int c = 0; c < OC1; ++c) {
+          lay[(size_t)3 * OC + OC1 + 2 * c] = lay[(size_t)3 * OC + OC1 + 2 * c + 1] = b1[c];
+          lay[(size_t)3 * OC + 3 * OC1 + 2 * c] = lay[(size_t)3 * OC + 3 * OC1 + 2 * c + 1] = s1[c];
+        }
+      } else {
+        memcpy(lay.data(), cst.data(), (size_t)OC * 4);  // A0
+        for (int c = 0; c < OC; ++c) {
+          lay[(size_t)OC + 2 * c] = lay[(size_t)OC + 2 * c + 1] = b0[c];
+          lay[(size_t)3 * OC + 2 * c] = lay[(size_t)3 * OC + 2 * c + 1] = s0[c];
+        }
+      }
+      cst.swap(lay);
+    }
     // one buffer in LDS-image order: [W0 fragments | W1 fragments | constants]
     const size_t cbytes = round16(cst.size() * 4);
     if (!h->d_wei) HIP_TRY(hipMalloc(&h->d_wei, nw0 + nw1 + cbytes));
@@ -1108,17 +1276,23 @@ int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei, const void *bia0, con
 int dfx_conv_submit(dfx_conv_t *h, const void *src_dev, void *dst_dev, dfx_stream_t s) {
   if (!h || !src_dev || !dst_dev) return fail(DFX_ERR_INVALID, "conv_submit: null argument");
   if (!h->weights_set) return fail(DFX_ERR_STATE, "conv_submit: dfx_conv_set_weights not called");
+  DeviceGuard dg(h->device);
   if (h->split0) {
     int rc0 = dfx_conv_submit(h->split0, src_dev, h->d_mid, s);
     return rc0 != DFX_OK ? rc0 : dfx_conv_submit(h->split1, h->d_mid, dst_dev, s);
   }
-  h->args.src = (const uint8_t *)src_dev;
-  h->args.dst = dst_dev;
+  // per-launch copies: concurrent submits of one handle (other host threads, other streams) share
+  // only immutable state and each takes its own unit-queue slot of the ring
+  ConvArgs a = h->args;
+  a.src = (const uint8_t *)src_dev;
+  a.dst = dst_dev;
+  MfmaGeom g = h->geom;
+  if (g.queue) g.queue += 2 * (__atomic_fetch_add(&h->launch_seq, 1u, __ATOMIC_RELAXED) % DFX_QUEUE_RING);
   int rc;
   if (h->variant != DFX_VARIANT_GENERIC)
-    rc = mfma_dispatch(h, (hipStream_t)s, 0);
+    rc = mfma_dispatch(h, a, g, (hipStream_t)s, 0);
   else
-    rc = launch_conv_generic(h->args, (hipStream_t)s, nullptr, nullptr);
+    rc = launch_conv_generic(a, (hipStream_t)s, nullptr, nullptr);
   if (rc != 0) return fail(DFX_ERR_UNSUPPORTED, "conv_submit: no kernel instance for this op");
   HIP_TRY(hipGetLastError());
   return DFX_OK;
@@ -1131,6 +1305,7 @@ static size_t conv_dst_bytes(const dfx_conv_desc &d) {
 
 int dfx_conv_submit_host(dfx_conv_t *h, const void *src_host, void *dst_host) {
   if (!h || !src_host || !dst_host) return fail(DFX_ERR_INVALID, "conv_submit_host: null argument");
+  DeviceGuard dg(h->device);
   const size_t sb = conv_src_bytes(h->d), db = conv_dst_bytes(h->d);
   if (!h->d_src) {
     HIP_TRY(hipMalloc(&h->d_src, sb));
@@ -1152,6 +1327,7 @@ int dfx_conv_query(const dfx_conv_t *h, dfx_conv_info *info) {
   info->variant = h->variant;
   info->grid = h->grid; info->block = h->block; info->lds_bytes = h->lds;
   info->rows_per_unit = h->args.rows_per_unit;
+  info->device = h->device;
   const uint64_t px = (uint64_t)d.bs * d.oh * d.ow;
   const uint64_t mac = px * ((uint64_t)d.oc * d.ic * d.kh * d.kw + (uint64_t)d.oc1x1 * d.oc);
   info->algorithmic_ops = 2 * mac;
@@ -1170,6 +1346,11 @@ int dfx_debug_read_bounds(dfx_conv_t *h, long long *out) {
 }
 #endif
 
+#ifdef DFX_TRACE
+// diagnostic build only (make trace): host pointer to the [grid][16 waves][4] progress words
+int *dfx_debug_trace(dfx_conv_t *h) { return h ? h->trace_host : nullptr; }
+#endif
+
 #ifdef DFX_STAMPS
 // diagnostic build only: copies the [grid][8 waves][8] stamp sums of the last launch
 int dfx_debug_read_stamps(dfx_conv_t *h, unsigned long long *out, int max_entries) {
@@ -1183,6 +1364,20 @@ int dfx_debug_read_stamps(dfx_conv_t *h, unsigned long long *out, int max_entrie
 
 int dfx_conv_destroy(dfx_conv_t *h) {
   conv_release(h);
+  return DFX_OK;
+}
+
+// test hook: set (value != NULL) or clear one of the testing / tuning switches of DESIGN.md
+// section 9 after the environment has been read; affects handles created afterwards
+int dfx_debug_set_tuning(const char *key, const char *value) {
+  if (!key) return fail(DFX_ERR_INVALID, "set_tuning: null key");
+  bool known = false;
+  for (const char *k : kTuningKeys) known = known || strcmp(k, key) == 0;
+  if (!known) return fail(DFX_ERR_INVALID, "set_tuning: unknown switch %s", key);
+  Tuning &t = tuning();
+  std::lock_guard<std::mutex> lk(t.mu);
+  if (value) t.kv[key] = value;
+  else t.kv.erase(key);
   return DFX_OK;
 }
 
@@ -1209,6 +1404,7 @@ int dfx_concat_create(const dfx_concat_desc *desc, dfx_concat_t **out) {
   dfx_concat *h = new (std::nothrow) dfx_concat();
   if (!h) return fail(DFX_ERR_HIP, "out of host memory");
   h->d = d;
+  if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
   h->channels.assign(d.channels, d.channels + d.n_inputs);
   h->d.channels = h->channels.data();
   h->d_dst = nullptr;
@@ -1232,6 +1428,7 @@ int dfx_concat_create(const dfx_concat_desc *desc, dfx_concat_t **out) {
 
 int dfx_concat_submit(dfx_concat_t *h, const void *const *srcs_dev, void *dst_dev, dfx_stream_t s) {
   if (!h || !srcs_dev || !dst_dev) return fail(DFX_ERR_INVALID, "concat_submit: null argument");
+  DeviceGuard dg(h->device);
   for (int i = 0; i < h->d.n_inputs; ++i) {
     if (!srcs_dev[i]) return fail(DFX_ERR_INVALID, "concat_submit: null input %d", i);
     h->args.src[i] = (const unsigned char *)srcs_dev[i];
@@ -1256,6 +1453,7 @@ int dfx_concat_submit_gathered(dfx_concat_t *h, const void *gathered_dev, const 
 
 int dfx_concat_submit_host(dfx_concat_t *h, const void *const *srcs_host, void *dst_host) {
   if (!h || !srcs_host || !dst_host) return fail(DFX_ERR_INVALID, "concat_submit_host: null argument");
+  DeviceGuard dg(h->device);
   const size_t px = (size_t)h->d.bs * h->d.h * h->d.w, es = dt_size(h->d.dt);
   size_t oc = 0;
   for (int c : h->channels) oc += c;
@@ -1277,6 +1475,7 @@ int dfx_concat_submit_host(dfx_concat_t *h, const void *const *srcs_host, void *
 
 int dfx_concat_destroy(dfx_concat_t *h) {
   if (!h) return DFX_OK;
+  DeviceGuard dg(h->device);
   for (void *p : h->d_srcs) (void)hipFree(p);
   (void)hipFree(h->d_dst);
   if (h->host_stream) (void)hipStreamDestroy(h->host_stream);

@@ -20,6 +20,27 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// ---- 16-byte global stores.
+// gfx950 (ROCm 7.2): a VALU instruction that overwrites a data register of a global_store_dwordx4
+// ONE wait state after the store -- the padding hipcc uses -- can still change what is stored when
+// the memory pipeline is backed up (tools/probe/probe_store_war.hip: ~0.5 % of store-bound stores
+// wrong at 1 wait state, none at 2; narrower stores and LDS stores are interlocked).  Every 16-byte
+// global store of this library goes through dfx_store16*: the asm statement after the store keeps
+// the data registers live (an input operand) and is itself 2 wait states, so no instruction can
+// overwrite them any earlier.  tests/test_isa_hazards_cpu.py checks the built library for it. ----
+template <class V>
+__device__ __forceinline__ void dfx_store16(V *p, V v) {
+  static_assert(sizeof(V) == 16, "16-byte vector types only");
+  *p = v;
+  asm volatile("s_nop 1" ::"v"(v) : "memory");
+}
+template <class V>
+__device__ __forceinline__ void dfx_store16_nt(V *p, V v) {  // non-temporal: written once, never re-read here
+  static_assert(sizeof(V) == 16, "16-byte vector types only");
+  __builtin_nontemporal_store(v, p);
+  asm volatile("s_nop 1" ::"v"(v) : "memory");
+}
+
 // vmaxps(dst, zero, v)
 __device__ __forceinline__ float relu_x86(float v) { return (0.0f > v) ? 0.0f : v; }
 

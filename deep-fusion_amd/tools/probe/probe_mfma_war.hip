@@ -187,6 +187,48 @@ __global__ __launch_bounds__(1024) void k_Bm(int niter, unsigned long long *bad,
   if (nbx) atomicAdd(bad + 2, nbx);
 }
 
+// VALU write-after-read: a v_mov overwrites one register of SrcA / SrcB of the MFMA issued just
+// before it (hipcc emits this shape: the address of the next fragment load is computed into the
+// fragment's own first register); the register is restored before the next use
+#define VWAR_KERNEL(NAME, SRCS, GAP, RELOADED_IS_A)                                                \
+  __global__ __launch_bounds__(1024) void NAME(int niter, unsigned long long *bad, unsigned seed) { \
+    __shared__ __attribute__((aligned(16))) unsigned char frag[16 * 4096];                        \
+    const Setup u = setup(frag, seed);                                                            \
+    const v16i z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                                \
+    const v16i r0 = RELOADED_IS_A ? __builtin_amdgcn_mfma_i32_32x32x32_i8(u.f0, u.fo, z, 0, 0, 0)  \
+                                  : __builtin_amdgcn_mfma_i32_32x32x32_i8(u.fo, u.f0, z, 0, 0, 0); \
+    unsigned long long nb0 = 0, nb1 = 0;                                                          \
+    for (int it = 0; it < niter; ++it) {                                                          \
+      v16i d0, d1;                                                                                \
+      int t0 = (int)u.a0 * 77 + it;                                                               \
+      asm volatile("v_mov_b32 v120, %3\n\tv_mov_b32 v121, %4\n\tv_mov_b32 v122, %5\n\tv_mov_b32 v123, %6\n\t" \
+                   "s_nop 7\n\t"                                                                  \
+                   "v_mfma_i32_32x32x32_i8 %0, " SRCS ", 0\n\t" GAP                               \
+                   "v_mov_b32 v120, %7\n\t"            /* clobbers register 0 of the quad */      \
+                   "s_nop 7\n\t"                                                                  \
+                   "v_mov_b32 v120, %3\n\t"            /* restore */                              \
+                   "s_nop 7\n\t"                                                                  \
+                   "v_mfma_i32_32x32x32_i8 %1, " SRCS ", 0\n\t" GAP                               \
+                   "v_mov_b32 v120, %7\n\t"                                                       \
+                   "s_nop 15\n\ts_nop 15\n\t"                                                    \
+                   : "=&v"(d0), "=&v"(d1)                                                         \
+                   : "v"(u.fo), "v"(u.f0[0]), "v"(u.f0[1]), "v"(u.f0[2]), "v"(u.f0[3]), "v"(t0)   \
+                   : "v120", "v121", "v122", "v123", "memory");                                   \
+      if (!same(d0, r0)) ++nb0;                                                                   \
+      if (!same(d1, r0)) ++nb1;                                                                   \
+    }                                                                                             \
+    if (nb0) atomicAdd(bad, nb0);                                                                 \
+    if (nb1) atomicAdd(bad + 1, nb1);                                                             \
+  }
+VWAR_KERNEL(k_vA_none, "v[120:123], %2", "", true)
+VWAR_KERNEL(k_vA_nop0, "v[120:123], %2", "s_nop 0\n\t", true)
+VWAR_KERNEL(k_vA_nop1, "v[120:123], %2", "s_nop 1\n\t", true)
+VWAR_KERNEL(k_vA_nop3, "v[120:123], %2", "s_nop 3\n\t", true)
+VWAR_KERNEL(k_vB_none, "%2, v[120:123]", "", false)
+VWAR_KERNEL(k_vB_nop0, "%2, v[120:123]", "s_nop 0\n\t", false)
+VWAR_KERNEL(k_vB_nop1, "%2, v[120:123]", "s_nop 1\n\t", false)
+VWAR_KERNEL(k_vB_nop3, "%2, v[120:123]", "s_nop 3\n\t", false)
+
 typedef void (*kern_t)(int, unsigned long long *, unsigned);
 struct Cfg { const char *name; kern_t k; const char *what; };
 
@@ -214,6 +256,14 @@ int main(int argc, char **argv) {
       {"A_nop3", k_A_nop3, "SrcA, s_nop 3"},
       {"A_nop7", k_A_nop7, "SrcA, s_nop 7"},
       {"B_mfma", k_Bm, "SrcB, one independent MFMA of the same wave in between"},
+      {"valuA_none", k_vA_none, "v_mov overwrites a register of SrcA, 0 wait states after the MFMA"},
+      {"valuA_nop0", k_vA_nop0, "VALU write to SrcA, s_nop 0 (1 wait state)"},
+      {"valuA_nop1", k_vA_nop1, "VALU write to SrcA, s_nop 1 (2 wait states)"},
+      {"valuA_nop3", k_vA_nop3, "VALU write to SrcA, s_nop 3 (4 wait states)"},
+      {"valuB_none", k_vB_none, "v_mov overwrites a register of SrcB, 0 wait states after the MFMA"},
+      {"valuB_nop0", k_vB_nop0, "VALU write to SrcB, s_nop 0 (1 wait state)"},
+      {"valuB_nop1", k_vB_nop1, "VALU write to SrcB, s_nop 1 (2 wait states)"},
+      {"valuB_nop3", k_vB_nop3, "VALU write to SrcB, s_nop 3 (4 wait states)"},
       {"ctl", k_ctl, "control: load targets a source of the MFMA BEFORE the preceding one"},
   };
   hipEvent_t e0, e1;

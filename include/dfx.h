@@ -81,7 +81,7 @@ typedef struct dfx_conv_info {
   int32_t variant;
   int32_t grid, block, lds_bytes;
   int32_t rows_per_unit;       /* output rows one workgroup produces */
-  int32_t reserved;
+  int32_t device;              /* ordinal of the device the handle lives on */
   uint64_t algorithmic_ops;    /* 2*MAC of one submit */
   uint64_t algorithmic_bytes;  /* src + weights + dst bytes of one submit */
   char kernel_name[96];
@@ -98,6 +98,7 @@ typedef struct dfx_concat_desc {
 typedef struct dfx_conv dfx_conv_t;
 typedef struct dfx_concat dfx_concat_t;
 typedef void *dfx_stream_t; /* a hipStream_t; NULL = the default stream */
+typedef void *dfx_event_t;  /* a hipEvent_t */
 
 /* ---- library / device ---- */
 int dfx_version(void);
@@ -118,6 +119,14 @@ int dfx_memset_device(void *dst_dev, int value, size_t bytes, dfx_stream_t s);
 int dfx_stream_create(dfx_stream_t *s);
 int dfx_stream_destroy(dfx_stream_t s);
 int dfx_stream_sync(dfx_stream_t s);
+/* work enqueued on `waiter` after this call starts only when everything enqueued on `producer`
+ * before it has finished (chains of asynchronous submits on different streams) */
+int dfx_stream_wait_stream(dfx_stream_t waiter, dfx_stream_t producer);
+/* device-side timing (the DEEPFUSION_PROFILE hook of op::submit, deepfusion.cc:91-102) */
+int dfx_event_create(dfx_event_t *e);
+int dfx_event_record(dfx_event_t e, dfx_stream_t s);
+int dfx_event_elapsed_ms(dfx_event_t start, dfx_event_t stop, float *ms); /* waits for `stop` */
+int dfx_event_destroy(dfx_event_t e);
 
 /* ---- weight reorder (the reference exposes OIhw4i16o4i, deepfusion.h:59-60,
  *      but ships no reorder, deepfusion.cc:44-50).  Host-side, pure layout. ---- */
@@ -131,6 +140,9 @@ size_t dfx_blocked_offset(int o, int i, int kh, int kw, int I, int KH, int KW);
  * (op_conv.cc:262-365, jit_conv_kernel.cc:512-673) minus the defects of
  * SURVEY.md 8(a); picks a kernel variant. */
 int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out);
+/* A handle lives on the device that was current (dfx_set_device) when it was created; every
+ * later entry point switches to that device for the duration of the call, so one host thread can
+ * drive handles on several devices. */
 /* host pointers; data is copied (and repacked for the MFMA variant) into
  * device memory owned by the handle.  wei1x1/bia1x1/scales1 are ignored for an
  * unfused op; bias pointers may be NULL when the dtype is DFX_UNDEF. */
@@ -138,7 +150,11 @@ int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei_blocked, const void *b
                          const float *scales0, const int8_t *wei1x1_blocked,
                          const void *bia1, const float *scales1);
 /* asynchronous: enqueues on `s`; src_dev/dst_dev are device pointers that must
- * stay valid until the stream reaches the kernel's end. */
+ * stay valid until the stream reaches the kernel's end.  A handle may be submitted from several
+ * host threads and on several streams at once: every launch works on its own copy of the
+ * arguments and its own unit-queue slot (up to 16 launches of one handle in flight).  The one
+ * exception is an op whose dfx_conv_info.kernel_name starts with "split:" (two launches through
+ * a handle-owned intermediate): keep its submits on one stream. */
 int dfx_conv_submit(dfx_conv_t *h, const void *src_dev, void *dst_dev, dfx_stream_t s);
 /* drop-in semantics of op::submit() (deepfusion.cc:90-103): host buffers in,
  * host buffers out, synchronous (H2D, kernel, D2H, stream sync). */
@@ -163,6 +179,11 @@ int dfx_concat_destroy(dfx_concat_t *h);
 /* Overwrites the LDS of every CU with a pattern (asynchronous, on `s`): makes a kernel that
  * reads LDS before publishing it fail deterministically (tests/test_gpu_first_launch.py). */
 int dfx_debug_scribble_lds(unsigned pattern, dfx_stream_t s);
+/* Sets (value != NULL) or clears a testing / tuning switch (DFX_NO_FAST,
+ * DFX_FORCE_GEOM, DFX_STREAM_GRID ...).  The library reads those from the environment once, when
+ * it is first used; this is how a test reaches another code path afterwards.  Affects handles
+ * created after the call. */
+int dfx_debug_set_tuning(const char *key, const char *value);
 
 #ifdef __cplusplus
 }

@@ -38,11 +38,11 @@ n = L.dfx_debug_read_stamps(op._h, buf.ctypes.data_as(ctypes.c_void_p), buf.size
 p = buf[:n].reshape(info.grid, 2, 8, 16).astype(np.float64)
 comp = p[:, :, :7, :]
 print("kernel", info.kernel_name.decode(), "grid", info.grid, "rows/unit", info.rows_per_unit)
-units = comp[..., 7].mean()
-print("units per team (mean): %.2f (min %.0f max %.0f), tiles per compute wave: %.2f" % (
-    units, comp[..., 7].min(), comp[..., 7].max(), comp[..., 6].mean()))
-names = ["wait for tile", "conv0 MFMA", "requant0", "conv1+requant1+stores", "-", "whole unit"]
-print("start-up (entry -> unit loop): mean %.0f cycles, of which this wave's weight staging (loads + LDS writes) %.0f; rest = barrier wait" % (comp[..., 4].mean(), comp[..., 12].mean()))
+# slots (conv_mfma.cuh, DFX_ACC): 0 claim + wait for the unit's tile, 1 conv0, 2 requant0, 3 conv1 + requant1 + stores,
+# 4 start-up, 5 whole claim, 6 tiles computed, 7 claims made
+print("tiles per compute wave: mean %.2f (min %.0f max %.0f); claims per wave: %.2f" % (
+    comp[..., 6].mean(), comp[..., 6].min(), comp[..., 6].max(), comp[..., 7].mean()))
+print("start-up (entry -> claim loop): mean %.0f cycles, of which this wave's weight staging (loads + LDS writes) %.0f; rest = barrier wait" % (comp[..., 4].mean(), comp[..., 12].mean()))
 life = comp[..., 9] - comp[..., 8]
 ld = p[:, :, 7, :]
 print("loader waves: entry -> barrier %.0f cycles (max %.0f), in the barrier %.0f" % (ld[..., 13].mean(), ld[..., 13].max(), ld[..., 14].mean()))
@@ -50,19 +50,18 @@ print("wave lifetime entry->exit: mean %.0f  min %.0f  max %.0f cycles" % (life.
 rt = comp[..., 10]
 rte = comp[..., 11]
 print("s_memtime ticks per s_memrealtime tick (10 ns): %.2f  => s_memtime runs at %.0f MHz" % ((life / (rt - rte)).mean(), (life / (rt - rte)).mean() * 100))
-print("entry time spread over all compute waves: %.2f us; kernel span first entry -> last exit: %.2f us" % ((rte.max() - rte.min()) / 100.0, (rt.max() - rte.min()) / 100.0))
-print("exit time spread over all compute waves (s_memrealtime @100MHz): %.2f us; per-WG entry spread n/a" % ((rt.max() - rt.min()) / 100.0))
-ex = (rt.max() - rt.reshape(info.grid * 2, -1).max(axis=1)) / 100.0   # per team: idle us before the kernel ends
-print("team idle time before kernel end (us): mean %.2f  percentiles 10/50/90/100: %s  => %.1f%% of the span" % (ex.mean(), [round(float(v), 2) for v in np.percentile(ex, [10, 50, 90, 100])], 100 * ex.mean() / ((rt.max() - rte.min()) / 100.0)))
+print("kernel span first entry -> last exit: %.2f us; exit time spread over compute waves %.2f us" % ((rt.max() - rte.min()) / 100.0, (rt.max() - rt.min()) / 100.0))
+ex = (rt.max() - rt.reshape(info.grid, -1).max(axis=1)) / 100.0   # per CU: idle us before the kernel ends
+print("CU idle time before kernel end (us): mean %.2f  percentiles 10/50/90/100: %s  => %.1f%% of the span" % (ex.mean(), [round(float(v), 2) for v in np.percentile(ex, [10, 50, 90, 100])], 100 * ex.mean() / ((rt.max() - rte.min()) / 100.0)))
+wex = (rt.reshape(info.grid, -1).max(axis=1, keepdims=True) - rt.reshape(info.grid, -1)) / 100.0
+print("wave idle before its own CU's last wave exits (us): mean %.2f max %.2f" % (wex.mean(), wex.max()))
+tiles = comp[..., 6].sum()
+names = ["claim + wait for tile", "conv0 MFMA", "requant0", "conv1+requant1+stores"]
 tot = comp[..., 5].sum()
 for k, nm in enumerate(names):
-    if nm == "-":
-        continue
-    print("compute waves  %-24s %10.0f cycles/unit/wave  %5.1f%%" % (nm, comp[..., k].sum() / comp[..., 7].sum(),
-                                                                  100 * comp[..., k].sum() / tot))
-print("per-wave total in unit loop: mean %.0f  max %.0f cycles" % (comp[..., 5].mean(), comp[..., 5].max()))
+    print("compute waves  %-24s %10.0f cycles/tile  %5.1f%% of the claim loop" % (nm, comp[..., k].sum() / tiles, 100 * comp[..., k].sum() / tot))
+print("compute waves  %-24s %10.0f cycles/tile" % ("whole loop", tot / tiles))
 wg_life = life.reshape(info.grid, -1).max(axis=1)
 print("per-XCD (blockIdx % 8) mean WG lifetime:", [int(wg_life[x::8].mean()) for x in range(8)])
-print("per-XCD min/max:", [(int(wg_life[x::8].min()), int(wg_life[x::8].max())) for x in range(8)])
 q = np.percentile(wg_life, [0, 10, 50, 90, 100])
 print("WG lifetime percentiles 0/10/50/90/100:", [int(v) for v in q])

@@ -18,3 +18,29 @@ def oracle():
     from oracle import oracle as orc
     orc.build()
     return orc
+
+
+class _Tuning:
+    """monkeypatch-like handle on the library's testing switches (dfx_debug_set_tuning): the
+    library reads its environment once, so tests flip switches through the C ABI instead."""
+
+    def __init__(self):
+        import importlib
+        self._capi = importlib.import_module("deep-fusion_amd.capi")
+        self._set = []
+
+    def setenv(self, key, value):
+        self._capi.set_tuning(key, value)
+        self._set.append(key)
+
+    def undo(self):
+        for k in self._set:
+            self._capi.set_tuning(k, None)
+        self._set = []
+
+
+@pytest.fixture
+def tuning():
+    t = _Tuning()
+    yield t
+    t.undo()

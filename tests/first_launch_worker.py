@@ -35,6 +35,9 @@ def main():
         (replace(big, dst_dt=C.S32, bs=12), -1), (replace(big, dst_dt=C.F32, bs=12), -1),
         (C.unfused(replace(big, dst_dt=C.U8)), -1), (C.unfused(replace(big, dst_dt=C.S32, bs=12)), -1),
         (C.CONFIG2, -1), (replace(C.SMALL, dst_dt=C.S32), -1),
+        # all units from the device queue, tiles larger than the loader's register window
+        (C.unfused(C.REF_SHAPES[2]), -1), (C.REF_SHAPES[2], -1),
+        (C.unfused(C.ConvCase("first_w360", 3, 64, 40, 360, 64, 0, dst_dt=C.S32)), -1),
         (C.ConvCase("first_res3", 4, 128, 28, 28, 128, 512, dst_dt=C.U8, wide=True), V.VARIANT_MFMA_STREAM),
         (C.ConvCase("first_res3s", 2, 128, 28, 28, 128, 256, dst_dt=C.S32), V.VARIANT_MFMA_STREAM),
         (C.ConvCase("first_res4", 8, 256, 14, 14, 256, 1024, dst_dt=C.U8, wide=True), -1),
@@ -64,8 +67,9 @@ def main():
         r = ref.view(np.uint32) if ref.dtype == np.float32 else ref
         nbad = int((g != r).sum())
         bad += nbad
+        where = [tuple(int(v) for v in b) for b in np.argwhere(g != r)[:24]]
         results.append({"case": case.ident(), "kernel": name, "first_launch_of_kernel": first,
-                        "mismatches": nbad, "elements": int(g.size)})
+                        "mismatches": nbad, "elements": int(g.size), "where": where})
         op.close()
     print(json.dumps({"results": results, "total_mismatches": bad}))
     return 0 if bad == 0 else 1

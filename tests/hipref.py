@@ -60,5 +60,6 @@ def assert_bit_equal(got, ref, what=""):
     if not np.array_equal(g, r):
         bad = np.argwhere(g != r)
         i = tuple(bad[0])
-        raise AssertionError("%s: %d of %d elements differ; first at %s: got %r want %r" %
-                             (what, len(bad), g.size, i, got[i], ref[i]))
+        spread = ["axis %d: %s" % (ax, sorted(set(int(v) for v in bad[:, ax]))[:40]) for ax in range(bad.shape[1])]
+        raise AssertionError("%s: %d of %d elements differ; first at %s: got %r want %r; indices hit per axis: %s" %
+                             (what, len(bad), g.size, i, got[i], ref[i], "; ".join(spread)))

@@ -94,6 +94,26 @@ def test_resident_kernel_cooperative_first_tile(hip, oracle, case):
     hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), info.kernel_name.decode())
 
 
+MODE_CASES = [C.SMALL64, replace(C.SMALL64, dst_dt=C.S32), replace(C.SMALL, dst_dt=C.S8, relu1=False),
+              replace(C.CONFIG3_SMALL, dst_dt=C.U8), C.CONFIG3_SMALL, replace(C.CONFIG3_SMALL, dst_dt=C.F32, relu1=False),
+              replace(C.SMALL64, bia0_dt=C.F32, bia1_dt=C.F32), replace(C.SMALL64, bia0_dt=C.UNDEF, bia1_dt=C.U8, dst_dt=C.S32),
+              C.unfused(replace(C.CONFIG3_SMALL, dst_dt=C.U8)), C.unfused(replace(C.SMALL64, dst_dt=C.S32)),
+              C.unfused(replace(C.SMALL, dst_dt=C.F32, relu0=False))]
+
+
+@pytest.mark.parametrize("switch", ["DFX_NO_MAGIC", "DFX_NO_FAST"])
+@pytest.mark.parametrize("case", MODE_CASES, ids=lambda c: c.ident())
+def test_resident_kernel_requant_modes(hip, oracle, tuning, case, switch):
+    """the resident-weight kernel's three requant modes (conv_mfma.cuh header): the default
+    picks "magic" for these reference-range cases; the switches force "fast" (v_cvt_f32_i32
+    chain) and "exact" (x86 instruction chain) on the same inputs."""
+    tuning.setenv(switch, "1")
+    data = C.generate(case)
+    got, info = hip.hip_conv(case, data)
+    assert info.variant in (hip.dfa.VARIANT_MFMA_FUSED, hip.dfa.VARIANT_MFMA_CONV), info.kernel_name
+    hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), info.kernel_name.decode() + " " + switch)
+
+
 # streamed-weight MFMA variant (conv_stream.cuh): general shapes -- SURVEY.md 8(f) rank 3
 STREAM_SHAPES = [
     C.ConvCase("s2", 1, 16, 11, 9, 48, 80, stride=(2, 2)),
@@ -129,10 +149,10 @@ def test_stream_variant(hip, oracle, case):
     hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), info.kernel_name.decode())
 
 
-def test_stream_variant_exact_requant_path(hip, oracle, monkeypatch):
+def test_stream_variant_exact_requant_path(hip, oracle, tuning):
     """DFX_NO_FAST=1 (read at set_weights) forces the exact requant code path on inputs the
     fast-path proof would otherwise accept."""
-    monkeypatch.setenv("DFX_NO_FAST", "1")
+    tuning.setenv("DFX_NO_FAST", "1")
     for case in STREAM_SHAPES[:12] + C.dtype_matrix(C.SMALL) + [C.unfused(c) for c in C.dtype_matrix(C.SMALL)]:
         data = C.generate(case)
         got, info = hip.hip_conv(case, data, force_variant=hip.dfa.VARIANT_MFMA_STREAM)
@@ -140,10 +160,10 @@ def test_stream_variant_exact_requant_path(hip, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("grid", ["1", "3"])
-def test_stream_variant_many_units_per_workgroup(hip, oracle, monkeypatch, grid):
+def test_stream_variant_many_units_per_workgroup(hip, oracle, tuning, grid):
     """DFX_STREAM_GRID caps the grid so that every workgroup walks many units: covers the
     cross-unit tile / weight prefetch and the unit-to-unit LDS reuse."""
-    monkeypatch.setenv("DFX_STREAM_GRID", grid)
+    tuning.setenv("DFX_STREAM_GRID", grid)
     for case in STREAM_SHAPES + [C.CONFIG3_SMALL, C.unfused(C.CONFIG2), replace(C.CONFIG3_SMALL, dst_dt=C.U8, wide=True)]:
         data = C.generate(case)
         got, info = hip.hip_conv(case, data, force_variant=hip.dfa.VARIANT_MFMA_STREAM)
@@ -171,17 +191,17 @@ def test_stream_variant_full_size(hip, oracle, case):
 
 
 @pytest.mark.parametrize("planes", ["0", "1"])
-def test_stream_variant_resident_input_chunks(hip, oracle, monkeypatch, planes):
+def test_stream_variant_resident_input_chunks(hip, oracle, tuning, planes):
     """DFX_STREAM_PLANES: all 64-channel input chunks resident in LDS (staged once per work
     item) vs one chunk at a time, on inputs with several chunks."""
-    monkeypatch.setenv("DFX_STREAM_PLANES", planes)
+    tuning.setenv("DFX_STREAM_PLANES", planes)
     cases = [c for c in STREAM_SHAPES if c.ic > 64] + [
         C.ConvCase("ic192", 3, 192, 9, 12, 160, 144, dst_dt=C.U8, wide=True),
         C.ConvCase("ic320", 2, 320, 5, 6, 272, 0, dst_dt=C.S32, k=(1, 1), pad=(0, 0)),
         C.ConvCase("ic144s2", 2, 144, 11, 9, 64, 256, stride=(2, 2), dst_dt=C.S8, relu1=False)]
     for grid in ("", "2"):
         if grid:
-            monkeypatch.setenv("DFX_STREAM_GRID", grid)
+            tuning.setenv("DFX_STREAM_GRID", grid)
         for case in cases:
             data = C.generate(case)
             got, info = hip.hip_conv(case, data, force_variant=hip.dfa.VARIANT_MFMA_STREAM)
@@ -189,10 +209,10 @@ def test_stream_variant_resident_input_chunks(hip, oracle, monkeypatch, planes):
 
 
 @pytest.mark.parametrize("mode", ["DFX_STREAM_OCC_PAR", "DFX_STREAM_SPLIT"])
-def test_stream_variant_chunk_parallel_and_split(hip, oracle, monkeypatch, mode):
+def test_stream_variant_chunk_parallel_and_split(hip, oracle, tuning, mode):
     """(unit, output chunk) work items for unfused ops, and fused ops run as two such
     launches through a u8 intermediate: forced on shapes that would not pick them."""
-    monkeypatch.setenv(mode, "1")
+    tuning.setenv(mode, "1")
     cases = STREAM_SHAPES + C.dtype_matrix(C.SMALL) + [C.CONFIG3_SMALL, replace(C.CONFIG3_SMALL, dst_dt=C.U8, wide=True)]
     if mode == "DFX_STREAM_OCC_PAR":
         cases = [C.unfused(c) if c.oc1x1 else c for c in cases] + [
@@ -200,7 +220,7 @@ def test_stream_variant_chunk_parallel_and_split(hip, oracle, monkeypatch, mode)
             C.ConvCase("oc320s2", 2, 48, 9, 11, 320, 0, stride=(2, 2), dst_dt=C.F32)]
     for grid in ("", "2"):
         if grid:
-            monkeypatch.setenv("DFX_STREAM_GRID", grid)
+            tuning.setenv("DFX_STREAM_GRID", grid)
         for case in cases:
             data = C.generate(case)
             got, info = hip.hip_conv(case, data, force_variant=hip.dfa.VARIANT_MFMA_STREAM)
@@ -222,14 +242,14 @@ DIRECT_SHAPES = [
 
 
 @pytest.mark.parametrize("grid", ["", "2"])
-def test_direct_weight_kernel(hip, oracle, monkeypatch, grid):
+def test_direct_weight_kernel(hip, oracle, tuning, grid):
     """fused ops with >= 64 channels on both sides run on conv_direct.cuh (weights straight from
     L2 into MFMA operands); also with DFX_NO_FAST (exact requant path) and many units per workgroup."""
-    monkeypatch.setenv("DFX_STREAM_DIRECT", "1")   # (auto only picks it for deep first contractions)
+    tuning.setenv("DFX_STREAM_DIRECT", "1")   # (auto only picks it for deep first contractions)
     if grid:
-        monkeypatch.setenv("DFX_STREAM_GRID", grid)
+        tuning.setenv("DFX_STREAM_GRID", grid)
     for nofast in ("0", "1"):
-        monkeypatch.setenv("DFX_NO_FAST", nofast)
+        tuning.setenv("DFX_NO_FAST", nofast)
         for case in DIRECT_SHAPES + [C.CONFIG3_SMALL, replace(C.CONFIG3_SMALL, dst_dt=C.U8, wide=True)]:
             data = C.generate(case)
             got, info = hip.hip_conv(case, data, force_variant=hip.dfa.VARIANT_MFMA_STREAM)
@@ -439,10 +459,10 @@ def test_repeated_submits_rearm_queue(hip, oracle):
 
 
 @pytest.mark.parametrize("geom", ["1,56", "2,56", "3,56", "4,56", "5,56", "4,32", "2,32", "7,32"])
-def test_unit_geometries_and_tile_rotation(hip, oracle, geom, monkeypatch):
+def test_unit_geometries_and_tile_rotation(hip, oracle, geom, tuning):
     """every unit decomposition the host may pick (full-width linear units, 32-multiple
     column units, tile counts that do not divide the 7 compute waves) gives the same bytes."""
-    monkeypatch.setenv("DFX_FORCE_GEOM", geom)
+    tuning.setenv("DFX_FORCE_GEOM", geom)
     for case in (replace(C.CONFIG3_SMALL, bs=3), replace(C.CONFIG3_SMALL, bs=3, dst_dt=C.U8, wide=True)):
         data = C.generate(case)
         got, info = hip.hip_conv(case, data)
