@@ -139,10 +139,13 @@ struct MfmaGeom {  // unit decomposition chosen by the host (dfx_api.hip)
   int tile_chunks;  // (th + 2) * row_chunks
   unsigned row_magic;  // ceil(2^32 / row_chunks): q / row_chunks == umulhi(q, row_magic)
   unsigned tw_magic;   // ceil(2^32 / tw)
+  unsigned upi_magic, ux_magic;  // ceil(2^32 / (uy * ux)), ceil(2^32 / ux); 0 where the divisor is 1
   int ntu;             // tile claims per unit = tiles of a full unit
   unsigned ntu_magic;  // ceil(2^32 / ntu) (unused when ntu == 1)
   int claim_limit;     // ntu * (total_units + 4): no CU can legitimately claim more tiles
   int mode0, mode1;    // requant mode of stage 0 / stage 1: 0 exact, 1 fast, 2 magic (see header)
+  int s0_uniform;      // fused op with ONE conv0 scale (count 1, op_conv.cc:311-313): s0_value, no per-channel reads
+  float s0_value;
   int tile_stride;     // bytes between the MFMA_NB input-tile slots in LDS
   int static_rounds;   // units a loader owns statically before it turns to the queue
   int *queue;          // [0] next unit, [1] finished loaders; both 0 between launches
@@ -197,7 +200,7 @@ __device__ __forceinline__ float acc_to_f32(int raw, float comp, float bias) {
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 #ifndef DFX_RING
-#define DFX_RING 3  // conv0 fragment prefetch depth (k-steps in flight)
+#define DFX_RING 5  // conv0 fragment prefetch depth (k-steps in flight): LDS latency is several hundred cycles under load
 #endif
 
 // The output is written once and never re-read by this kernel: non-temporal stores
@@ -398,12 +401,15 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_entry)::"memory");
 #endif
   const int OC1 = FUSED ? a.oc1 : 0, NCB = OC1 >> 5, NCG = FUSED ? NCB / G : 1;
-  unsigned char *w0s = smem;                                   // [OCB][9][ICB][64 lanes][16 B]
+  // LDS: [control block | W0 fragments | W1 fragments | constants | MFMA_NB input tiles].  The control
+  // block sits at LDS address 0: ds_append takes its address from M0 + a 16-bit immediate, and only
+  // the form M0 = 0 is relied upon here.
+  int *ctrl = reinterpret_cast<int *>(smem);
+  unsigned char *w0s = smem + MFMA_CTRL_BYTES;                 // [OCB][9][ICB][64 lanes][16 B]
   unsigned char *w1s = w0s + OCB * 9 * ICB * 1024;             // [NCB][OCB][64 lanes][16 B]
   float *cst = reinterpret_cast<float *>(w1s + NCB * OCB * 1024);
   const int cst_bytes = (mfma_cst_floats(OC, OC1) * 4 + 15) & ~15;
-  int *ctrl = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(cst) + cst_bytes);
-  unsigned char *tiles = reinterpret_cast<unsigned char *>(ctrl) + MFMA_CTRL_BYTES;
+  unsigned char *tiles = reinterpret_cast<unsigned char *>(cst) + cst_bytes;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -414,31 +420,33 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
 
   // ---- halo-tile chunk helpers (loader waves; compute waves for the very first tiles) ----
   const v4i x80 = v4i{(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
-  // chunk q of a unit's halo tile: LDS row lr = q / row_chunks, chunk c within the row.
-  // Branch-free with CLAMPED, always-in-range coordinates: chunks outside the image (and
-  // chunk indices beyond the tile) read a valid pixel of the same image and are replaced by
-  // zeros (real 0 = the stored byte 0x80).
-  auto load_chunk = [&](const uint8_t *src_n, int y0, int x0, int q) {
+  // The halo tile in LDS is an array of 16-byte GRANULES in row-major (tile row, tile column, slot)
+  // order; slot `sl` of the pixel in tile column X holds the pixel's channel chunk sl ^ swz(X).
+  // Granule q of a unit, general form: branch-free with CLAMPED, always-in-range coordinates --
+  // granules outside the image read a valid pixel of the same image and are replaced by zeros
+  // (real 0 = the stored byte 0x80).  q must be < tile_chunks.
+  auto load_granule = [&](const uint8_t *src_n, int y0, int x0, int q) {
     const int lr = (int)__umulhi((unsigned)q, g.row_magic);
     const int c = q - lr * g.row_chunks;
-    const int iy = y0 + lr, ix = x0 + c / CP;
-    const bool ok = q < g.tile_chunks && iy >= 0 && iy < a.ih && ix >= 0 && ix < a.iw;
+    const int X = c / CP, j = (c % CP) ^ chunk_swizzle<CP>(X);
+    const int iy = y0 + lr, ix = x0 + X;
+    const bool ok = iy >= 0 && iy < a.ih && ix >= 0 && ix < a.iw;
     const int cy = min(max(iy, 0), a.ih - 1), cx = min(max(ix, 0), a.iw - 1);
-    const unsigned off = (unsigned)((cy * a.iw + cx) * IC + 16 * (c % CP));
+    const unsigned off = (unsigned)((cy * a.iw + cx) * IC + 16 * j);
     const v4i v = *reinterpret_cast<const v4i *>(src_n + off);
     return (ok ? v : v4i{0, 0, 0, 0}) ^ x80;  // stored form: u8 - 128; padding = 0x80
   };
-  // LDS byte offset of chunk q (unit independent); chunks beyond the tile go to a
-  // 16-byte dump slot right behind it so the write loop needs no predicate
-  auto chunk_lds_off = [&](int q) {
-    const int lr = (int)__umulhi((unsigned)q, g.row_magic);
-    const int c = q - lr * g.row_chunks;
-    const int X = c / CP;
-    return q < g.tile_chunks ? (lr * LW + X) * IC + 16 * ((c % CP) ^ chunk_swizzle<CP>(X)) : g.tile_chunks * 16;
+  // unit -> (image, unit row, unit column) with multiply-high instead of integer division (a unit id is
+  // < 2^31 / 64, far inside the range where ceil(2^32 / d) is exact)
+  auto unit_split = [&](int unit, int &n, int &uyi, int &uxi) {
+    n = g.upi_magic ? (int)__umulhi((unsigned)unit, g.upi_magic) : unit;
+    const int u = unit - n * upi;
+    uyi = g.ux_magic ? (int)__umulhi((unsigned)u, g.ux_magic) : u;
+    uxi = u - uyi * g.ux;
   };
   auto unit_origin = [&](int unit, const uint8_t *&src_n, int &y0, int &x0) {
-    const int n = unit / upi, u = unit - n * upi;
-    const int uyi = u / g.ux, uxi = u - uyi * g.ux;
+    int n, uyi, uxi;
+    unit_split(unit, n, uyi, uxi);
     y0 = uyi * g.th - a.pt;
     x0 = uxi * g.tw - a.pl;
     src_n = a.src + (size_t)n * a.ih * a.iw * IC;
@@ -446,8 +454,8 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
 
   // what a compute wave needs to know about a unit (the loader computes it once per unit)
   auto unit_info = [&](int unit, int &pix0, int &thtw, int &tprm) {
-    const int n = unit / upi, u = unit - n * upi;
-    const int uyi = u / g.ux, uxi = u - uyi * g.ux;
+    int n, uyi, uxi;
+    unit_split(unit, n, uyi, uxi);
     const int y0 = uyi * g.th, x0 = uxi * g.tw;
     const int th = min(g.th, a.oh - y0), tw = min(g.tw, a.ow - x0);
     const int tpr = (tw + 31) >> 5;
@@ -486,7 +494,7 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
     constexpr int TT = MFMA_CW * 64;  // threads of the 7 compute waves that stage one first tile
     const int ctid = (team * MFMA_CW + cw) * 64 + lane, tctid = cw * 64 + lane;
     const v4i *s = reinterpret_cast<const v4i *>(a.wei);
-    v4i *d = reinterpret_cast<v4i *>(smem);
+    v4i *d = reinterpret_cast<v4i *>(w0s);
     const int total = OCB * 9 * ICB * 64 + NCB * OCB * 64 + (mfma_cst_floats(OC, OC1) * 4 + 15) / 16;
     // first tile of stream `team` (coop0): ring slot `team`, unit blockIdx * 2 + team; its first
     // 4 chunks per thread travel together with the weights (one memory round trip for both)
@@ -504,33 +512,33 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
       const v4i t3 = s[min(q0 + 3 * NT, last)];
       v4i u0 = x80, u1 = x80, u2 = x80, u3 = x80;
       if (tile0 && base == 0) {
-        u0 = load_chunk(src_n, y0, x0, tctid + 0 * TT);
-        u1 = load_chunk(src_n, y0, x0, tctid + 1 * TT);
-        u2 = load_chunk(src_n, y0, x0, tctid + 2 * TT);
-        u3 = load_chunk(src_n, y0, x0, tctid + 3 * TT);
+        u0 = load_granule(src_n, y0, x0, min(tctid + 0 * TT, g.tile_chunks - 1));
+        u1 = load_granule(src_n, y0, x0, min(tctid + 1 * TT, g.tile_chunks - 1));
+        u2 = load_granule(src_n, y0, x0, min(tctid + 2 * TT, g.tile_chunks - 1));
+        u3 = load_granule(src_n, y0, x0, min(tctid + 3 * TT, g.tile_chunks - 1));
       }
       d[min(q0 + 0 * NT, last)] = t0;
       d[min(q0 + 1 * NT, last)] = t1;
       d[min(q0 + 2 * NT, last)] = t2;
       d[min(q0 + 3 * NT, last)] = t3;
       if (tile0 && base == 0) {
-        *reinterpret_cast<v4i *>(slot + chunk_lds_off(tctid + 0 * TT)) = u0;
-        *reinterpret_cast<v4i *>(slot + chunk_lds_off(tctid + 1 * TT)) = u1;
-        *reinterpret_cast<v4i *>(slot + chunk_lds_off(tctid + 2 * TT)) = u2;
-        *reinterpret_cast<v4i *>(slot + chunk_lds_off(tctid + 3 * TT)) = u3;
+        if (tctid + 0 * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (tctid + 0 * TT)) = u0;
+        if (tctid + 1 * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (tctid + 1 * TT)) = u1;
+        if (tctid + 2 * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (tctid + 2 * TT)) = u2;
+        if (tctid + 3 * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (tctid + 3 * TT)) = u3;
       }
     }
     if (tile0) {  // a tile of more than 4 chunks per thread: the rest
       for (int base = 4 * TT; base < g.tile_chunks; base += 4 * TT) {
         const int q0 = base + tctid;
-        const v4i t0 = load_chunk(src_n, y0, x0, q0 + 0 * TT);
-        const v4i t1 = load_chunk(src_n, y0, x0, q0 + 1 * TT);
-        const v4i t2 = load_chunk(src_n, y0, x0, q0 + 2 * TT);
-        const v4i t3 = load_chunk(src_n, y0, x0, q0 + 3 * TT);
-        *reinterpret_cast<v4i *>(slot + chunk_lds_off(q0 + 0 * TT)) = t0;
-        *reinterpret_cast<v4i *>(slot + chunk_lds_off(q0 + 1 * TT)) = t1;
-        *reinterpret_cast<v4i *>(slot + chunk_lds_off(q0 + 2 * TT)) = t2;
-        *reinterpret_cast<v4i *>(slot + chunk_lds_off(q0 + 3 * TT)) = t3;
+        const v4i t0 = load_granule(src_n, y0, x0, min(q0 + 0 * TT, g.tile_chunks - 1));
+        const v4i t1 = load_granule(src_n, y0, x0, min(q0 + 1 * TT, g.tile_chunks - 1));
+        const v4i t2 = load_granule(src_n, y0, x0, min(q0 + 2 * TT, g.tile_chunks - 1));
+        const v4i t3 = load_granule(src_n, y0, x0, min(q0 + 3 * TT, g.tile_chunks - 1));
+        if (q0 + 0 * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (q0 + 0 * TT)) = t0;
+        if (q0 + 1 * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (q0 + 1 * TT)) = t1;
+        if (q0 + 2 * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (q0 + 2 * TT)) = t2;
+        if (q0 + 3 * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (q0 + 3 * TT)) = t3;
       }
     }
     if (ctid < MFMA_CTRL_BYTES / 4) {
@@ -558,19 +566,76 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
 
   if (cw == MFMA_CW) {
     // =========================== loader wave `team` ===========================
-    // owns k = team, team + 2, ...: ring slot k % 4 = 2 * (j & 1) + team for its j-th unit
+    // owns k = team, team + 2, ...: ring slot k % 4 = 2 * (j & 1) + team for its j-th unit.
+    // Highest issue priority: the loaders execute ~300 instructions per unit against the compute
+    // waves' thousands, but as the youngest waves of their SIMDs they lost every arbitration and
+    // needed ~10 k cycles per unit for them (profiles/stamps.py), which left the 14 compute waves
+    // waiting for tiles 40 % of the time.
+    __builtin_amdgcn_s_setprio(3);
     v4i pf[MFMA_LC];
-    // issue-early half: first 64*MFMA_LC chunks of a unit -> registers
+    // Per-lane tables for granule lane + 64 i (fixed for the whole launch):
+    //   rel[i]   byte offset of its SOURCE chunk from the unit's first halo pixel (tile row 0, column 0)
+    // FAST units -- every tile row inside the image with a row to spare above and below, full width:
+    // the 22 loads are then base + rel[i] with a scalar base and no further arithmetic; the (at most two)
+    // padding columns read the neighbouring row's pixels instead of zeros and are overwritten after
+    // the tile has been written (padfix).  Other units (image borders) take the general, clamped form.
+    // (kept as 16-bit granule offsets, two per register: with the 88 data registers a full 32-bit
+    // table spills to scratch, and every reload then waits for all loads in flight)
+    static_assert(MFMA_LC % 2 == 0, "rel table packs two entries per register");
+    unsigned relp[MFMA_LC / 2];
+#pragma unroll
+    for (int i = 0; i < MFMA_LC; ++i) {
+      const int q = min(lane + 64 * i, g.tile_chunks - 1);
+      const int lr = (int)__umulhi((unsigned)q, g.row_magic);
+      const int c = q - lr * g.row_chunks;
+      const int X = c / CP;
+      const unsigned r16 = (unsigned)((lr * a.iw + X) * CP + ((c % CP) ^ chunk_swizzle<CP>(X)));
+      if (i % 2 == 0) relp[i / 2] = r16 & 0xffffu;
+      else relp[i / 2] |= r16 << 16;
+    }
+    // padfix entries e = lane, lane + 64: (side, tile row, slot) -> LDS byte offset of that granule
+    const int pad_half = (g.th + 2) * CP;
+    int padoff[2], padside[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int e = lane + 64 * m, side = e >= pad_half ? 1 : 0, r = e - side * pad_half;
+      padside[m] = e < 2 * pad_half ? side : 2;  // 2 = no entry
+      padoff[m] = (((r / CP) * LW + (side ? LW - 1 : 0)) * CP + (r % CP)) * 16;
+    }
+    const bool fast_ok = 2 * pad_half <= 128 && (g.th + 2) * a.iw * CP < 65536;
+    auto unit_fast = [&](int unit, const uint8_t *&base_u, int &left, int &right) {
+      const uint8_t *src_n;
+      int y0, x0;
+      unit_origin(unit, src_n, y0, x0);
+      base_u = src_n + ((long long)y0 * a.iw + x0) * IC;
+      left = x0 < 0;
+      right = x0 + LW - 1 >= a.iw;
+      return fast_ok && y0 >= 1 && y0 + g.th + 1 <= a.ih - 2 && x0 >= -1 && x0 + LW - 1 <= a.iw;
+    };
+    int cur_fast = 0, cur_left = 0, cur_right = 0;
+    // issue-early half: first 64*MFMA_LC granules of a unit -> registers
 #define DFX_PREFETCH(UNIT)                                                              \
   do {                                                                                  \
-    const uint8_t *src_n_;                                                              \
-    int y0_, x0_;                                                                       \
-    unit_origin((UNIT), src_n_, y0_, x0_);                                              \
-    int lq_ = lane; /* opaque: keep the per-chunk index math out of the LICM set */     \
-    asm volatile("" : "+v"(lq_));                                                       \
-    _Pragma("unroll") for (int i = 0; i < MFMA_LC; ++i) pf[i] =                         \
-        load_chunk(src_n_, y0_, x0_, lq_ + 64 * i);                                     \
+    const uint8_t *base_u_;                                                             \
+    cur_fast = unit_fast((UNIT), base_u_, cur_left, cur_right) ? 1 : 0;                 \
+    if (cur_fast) {                                                                     \
+      /* unconditional (rel is clamped into the tile): a load inside a branch makes hipcc wait vmcnt(0) there */ \
+      _Pragma("unroll") for (int i = 0; i < MFMA_LC; ++i) {                             \
+        unsigned rp_ = relp[i / 2]; /* opaque: unpacked here, not hoisted (and spilled) */ \
+        asm volatile("" : "+v"(rp_));                                                   \
+        pf[i] = *reinterpret_cast<const v4i *>(base_u_ + ((i % 2 ? rp_ >> 16 : rp_ & 0xffffu) << 4)); \
+      }                                                                                 \
+    } else {                                                                            \
+      const uint8_t *src_n_;                                                            \
+      int y0_, x0_;                                                                     \
+      unit_origin((UNIT), src_n_, y0_, x0_);                                            \
+      int lq_ = lane; /* opaque: keep the per-granule index math out of the LICM set */ \
+      asm volatile("" : "+v"(lq_));                                                     \
+      _Pragma("unroll") for (int i = 0; i < MFMA_LC; ++i)                               \
+          pf[i] = load_granule(src_n_, y0_, x0_, min(lq_ + 64 * i, g.tile_chunks - 1)) ^ x80; \
+    }                                                                                   \
   } while (0)
+    // (the general form leaves pf as u8 with zero padding, like the fast form: the write applies ^ 0x80)
     // Unit sequence of this loader: the first `static_rounds` units are owned
     // statically (round j -> unit j*T + stream id; no atomic: 2 x gridDim loaders
     // hammering one queue word at kernel start cost ~12 us), the rest come from the
@@ -595,9 +660,6 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
     int nxt_v = unit_at(j0 + 1);
     int jn = j0 + 2;
     if (cur < g.total_units) DFX_PREFETCH(cur);  // (!coop0: the first tile's loads fly during the weight copy)
-    int wr_off[MFMA_LC];  // (computed while those loads are in flight)
-#pragma unroll
-    for (int i = 0; i < MFMA_LC; ++i) wr_off[i] = chunk_lds_off(lane + 64 * i);
     if (!coop0) __syncthreads();  // the only workgroup barrier: weights + control block are in LDS
     DFX_STAMP(l_post);
 #ifdef DFX_STAMPS
@@ -609,7 +671,11 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
 #endif
 
     DFX_TRACE_AT(100, cur, j0);
+#ifdef DFX_STAMPS
+    unsigned long long lacc[4] = {0, 0, 0, 0};  // slot wait, tile write + publish, next draw + prefetch issue, units
+#endif
     for (int j = j0;; ++j) {
+      DFX_STAMP(la);
       const int s = 2 * (j & 1) + team, gen = j >> 1;
       DFX_TRACE_AT(101, cur, j);
       unsigned char *ins = tiles + (size_t)s * g.tile_stride;
@@ -621,14 +687,26 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
       // slot s is free once every tile claim of its previous generation was counted off
       for (int spin = 0; spin < MFMA_SPIN_LIMIT && ctl_load(CTL_DONE + s) < 64 * g.ntu * gen; ++spin)
         __builtin_amdgcn_s_sleep(2);
+      DFX_STAMP(lb);
+      {  // write-late half of the staging: granule lane + 64 i -> LDS byte 16 * (lane + 64 i)
+        // (branch-free: pieces beyond the tile go to the 1 KB dump piece behind it)
+        unsigned char *dst = ins + lane * 16;
+        const int dump = g.tile_stride - 1024;
 #pragma unroll
-      for (int i = 0; i < MFMA_LC; ++i)   // write-late half of the staging
-        *reinterpret_cast<v4i *>(ins + wr_off[i]) = pf[i];
+        for (int i = 0; i < MFMA_LC; ++i)
+          *reinterpret_cast<v4i *>(dst + (64 * i < g.tile_chunks ? 1024 * i : dump)) = pf[i] ^ x80;
+      }
       if (g.tile_chunks > 64 * MFMA_LC) {  // oversized tile: the rest is staged synchronously
         const uint8_t *src_n; int y0, x0;
         unit_origin(cur, src_n, y0, x0);
         for (int q = 64 * MFMA_LC + lane; q < g.tile_chunks; q += 64)
-          *reinterpret_cast<v4i *>(ins + chunk_lds_off(q)) = load_chunk(src_n, y0, x0, q);
+          *reinterpret_cast<v4i *>(ins + 16 * q) = load_granule(src_n, y0, x0, q);
+      }
+      if (cur_fast) {  // padding columns of a fast unit (after the tile writes: same wave, LDS keeps the order)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          if ((padside[m] == 0 && cur_left) || (padside[m] == 1 && cur_right))
+            *reinterpret_cast<v4i *>(ins + padoff[m]) = x80;
       }
       DFX_TRACE_AT(102, cur, j);
       {
@@ -642,10 +720,21 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
       // compiler keep them ahead of the flag store and waits for them to complete
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // all lanes' tile writes first
       ctl_store(CTL_FULL + s, gen + 1);
+      DFX_STAMP(lc);
       cur = __builtin_amdgcn_readfirstlane(nxt_v);
       nxt_v = unit_at(jn++);
       if (cur < g.total_units) DFX_PREFETCH(cur);
+      DFX_STAMP(ld);
+#ifdef DFX_STAMPS
+      lacc[0] += lb - la; lacc[1] += lc - lb; lacc[2] += ld - lc; lacc[3] += 1;
+#endif
     }
+#ifdef DFX_STAMPS
+    if (lane == 0) {
+      unsigned long long *o = g.prof + ((size_t)blockIdx.x * 16 + wave) * 16;
+      o[0] = lacc[0]; o[1] = lacc[1]; o[2] = lacc[2]; o[3] = lacc[3];
+    }
+#endif
 #undef DFX_PREFETCH
     // last loader out re-arms the queue for the next launch.  The draw still in
     // flight must have been performed before this loader counts itself out, or it
@@ -690,43 +779,67 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
   const unsigned long long startup_stage = t_staged - t_entry;
 #endif
   DFX_TRACE_AT(3, 0, 0);
-  // Tile claims: every lane adds 1 to the CU's counter, so one claim moves it by 64 and any lane's
-  // old value >> 6 is the claim (whether hipcc folds the 64 adds into one ds_add_rtn of 64, as it
-  // does, or not).  LDS round trips take ~1 k cycles while 14 waves stream fragments, so a wave
-  // draws its NEXT claim at the start of a tile and only looks at the result when the tile is done;
-  // a claim is always processed by the wave that drew it (a wave that leaves holds one beyond the end).
-  auto draw = [&]() {
-    return __hip_atomic_fetch_add(ctrl + CTL_NEXT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  // Tile claims.  ds_append returns the counter's old value to the whole wave (wave-uniform) and adds
+  // the number of active lanes, 64: claim = old value >> 6.  It is an ordinary LDS instruction with a
+  // returned value, so the wait for it sits where the value is first used.  LDS round trips take
+  // ~1 k cycles while 14 waves stream fragments, therefore the control traffic is software-pipelined
+  // two tiles deep: while tile i is computed, the claim of tile i + 2 and the look at the flags and
+  // the unit record of tile i + 1 are in flight.  A claim is always processed by the wave that drew
+  // it (a wave that leaves holds two, both beyond the end).
+  typedef __attribute__((address_space(3))) int lds_int;
+  auto draw = [&]() { return __builtin_amdgcn_ds_append((lds_int *)(ctrl + CTL_NEXT)); };
+  struct Look { int full, end; v4i info; };
+  // one batch of LDS reads: FULL first, then the slot's unit record (LDS serves a wave's reads in
+  // order and the loader wrote the record before FULL), then the stream's END
+  auto look = [&](int sl, int par) {
+    Look l;
+    l.full = __hip_atomic_load(ctrl + CTL_FULL + sl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // (three LDS word loads: a volatile vector load through a generic pointer becomes flat_load + s_waitcnt
+    // vmcnt(0), i.e. a wait for every outstanding output store)
+    l.info[0] = __hip_atomic_load(ctrl + CTL_INFO + 4 * sl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    l.info[1] = __hip_atomic_load(ctrl + CTL_INFO + 4 * sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    l.info[2] = __hip_atomic_load(ctrl + CTL_INFO + 4 * sl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    l.info[3] = 0;
+    l.end = __hip_atomic_load(ctrl + CTL_END + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return l;
   };
-  int t_ahead = draw();
+  auto split = [&](int t, int &k, int &ti) {
+    k = g.ntu == 1 ? t : (int)__umulhi((unsigned)t, g.ntu_magic);  // (ceil(2^32 / 1) does not fit 32 bits)
+    ti = t - k * g.ntu;
+  };
+  int c_ahead = draw();
+  int t = __builtin_amdgcn_readfirstlane(c_ahead) >> 6, k, ti;
+  c_ahead = draw();
+  split(t, k, ti);
+  Look lk = look(k & (MFMA_NB - 1), k & 1);
   for (;;) {
     DFX_STAMP(c0);
-    const int t = __builtin_amdgcn_readfirstlane(t_ahead) >> 6;
-    t_ahead = draw();
     DFX_TRACE_AT(4, t, g.claim_limit);
     if (t > g.claim_limit) break;  // cannot happen (a CU never claims more than every tile of the op): keeps a logic error from hanging the GPU
-    const int k = g.ntu == 1 ? t : (int)__umulhi((unsigned)t, g.ntu_magic);  // (ceil(2^32 / 1) does not fit 32 bits)
-    const int ti = t - k * g.ntu;
     const int s = k & (MFMA_NB - 1), gen = k >> 2, p = k & 1;
-    // one batch of LDS reads per look: FULL first, then the slot's unit record (LDS serves a wave's
-    // reads in order, and the loader wrote the record before FULL), then the stream's END
     bool have = false;
-    v4i info = {0, 0, 0, 0};
+    v4i info = lk.info;
     for (int spin = 0; spin < MFMA_SPIN_LIMIT; ++spin) {  // (bounded: a protocol error must not hang the GPU)
-      const int full = __hip_atomic_load(ctrl + CTL_FULL + s, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      info = *reinterpret_cast<const volatile v4i *>(ctrl + CTL_INFO + 4 * s);
-      const int end = __hip_atomic_load(ctrl + CTL_END + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (__builtin_amdgcn_readfirstlane(full) >= gen + 1) { have = true; break; }
-      if (__builtin_amdgcn_readfirstlane(end) <= k) break;
+      if (__builtin_amdgcn_readfirstlane(lk.full) >= gen + 1) { have = true; info = lk.info; break; }
+      if (__builtin_amdgcn_readfirstlane(lk.end) <= k) break;
       __builtin_amdgcn_s_sleep(1);
+      lk = look(s, p);
     }
-    DFX_TRACE_AT(5, t, have);
+    // next tile: its claim was drawn one tile ago; look at its unit now, draw the claim after it
+    const int t_cur = t, k_cur = k, ti_cur = ti;
+    (void)t_cur;
+    t = __builtin_amdgcn_readfirstlane(c_ahead) >> 6;
+    c_ahead = draw();
+    split(t, k, ti);
+    lk = look(k & (MFMA_NB - 1), k & 1);
+    DFX_TRACE_AT(5, t_cur, have);
     DFX_STAMP(c1);
-    DFX_ACC(0, c1 - c0);  // claim + wait for the tile's unit
+    DFX_ACC(0, c1 - c0);  // wait for the tile's unit (claims and looks are prefetched)
     if (!have) {  // stream p has no k-th unit; done when the other stream has none for k + 1 either
-      if (ctl_load(CTL_END + (p ^ 1)) <= k + 1) break;
+      if (ctl_load(CTL_END + (p ^ 1)) <= k_cur + 1) break;
       continue;
     }
+    const int ti_now = ti_cur;
     const unsigned char *ins = tiles + (size_t)s * g.tile_stride;
     const int pix0 = __builtin_amdgcn_readfirstlane(info[0]);
     const int thtw = __builtin_amdgcn_readfirstlane(info[1]);
@@ -736,19 +849,19 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
     const int ntiles = g.linear ? (npx + 31) >> 5 : th * tiles_per_row;
 
     DFX_TRACE_AT(6, pix0, ntiles);
-    if (ti < ntiles) {
+    if (ti_now < ntiles) {
       // pixel of this lane (conv0 column) and the tile's output base (wave-uniform)
       int ty, tx, nvalid;
       size_t obase;  // dst pixel index of px_local == 0
       if (g.linear) {
-        nvalid = min(32, npx - 32 * ti);
-        const int pc = 32 * ti + min(l31, nvalid - 1);
+        nvalid = min(32, npx - 32 * ti_now);
+        const int pc = 32 * ti_now + min(l31, nvalid - 1);
         ty = tw == 1 ? pc : (int)__umulhi((unsigned)pc, g.tw_magic);  // tw == g.tw in linear mode
         tx = pc - ty * tw;
-        obase = (size_t)pix0 + 32 * ti;
+        obase = (size_t)pix0 + 32 * ti_now;
       } else {
         const int tprm = __builtin_amdgcn_readfirstlane(info[2]);
-        const int tr = tprm ? (int)__umulhi((unsigned)ti, (unsigned)tprm) : ti, tc = ti - tr * tiles_per_row;
+        const int tr = tprm ? (int)__umulhi((unsigned)ti_now, (unsigned)tprm) : ti_now, tc = ti_now - tr * tiles_per_row;
         nvalid = min(32, tw - 32 * tc);
         ty = tr;
         tx = 32 * tc + min(l31, nvalid - 1);
@@ -857,7 +970,23 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
       DFX_ACC(1, c3 - c2);  // conv0 MFMA issue
       // ---- requant 0 in registers -> A fragments of the 1x1 ----
       v4i mid[OCB];
-      if (mode0 == 2) {  // accumulator bits are the float 1.5 * 2^23 + acc + bias: subtract, scale, pack
+      if (mode0 == 2 && g.s0_uniform) {  // the same with the op's single scale in scalar registers
+        const v2f sc2 = {g.s0_value, g.s0_value};
+#pragma unroll
+        for (int r = 0; r < OCB; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            unsigned pk = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+              v2f x = {__int_as_float(acc0[r][4 * q + i]), __int_as_float(acc0[r][4 * q + i + 1])};
+              x = (x + v2f{-MAGIC0_F, -MAGIC0_F}) * sc2;
+              pk = __builtin_amdgcn_cvt_pk_u8_f32(x[0], i, pk);
+              pk = __builtin_amdgcn_cvt_pk_u8_f32(x[1], i + 1, pk);
+            }
+            mid[r][q] = (int)(pk ^ 0x80808080u);
+          }
+      } else if (mode0 == 2) {  // accumulator bits are the float 1.5 * 2^23 + acc + bias: subtract, scale, pack
 #pragma unroll
         for (int r = 0; r < OCB; ++r)
 #pragma unroll
@@ -971,7 +1100,7 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
       }  // FUSED
       DFX_ACC(6, 1);
     }
-    DFX_TRACE_AT(7, t, 0);
+    DFX_TRACE_AT(7, t_cur, 0);
     DFX_STAMP(c6);
     // count this claim off on its slot (the tile's LDS reads have been consumed by the MFMAs)
     __hip_atomic_fetch_add(ctrl + CTL_DONE + s, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // all 64 lanes: + 64

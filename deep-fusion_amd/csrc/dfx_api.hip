@@ -348,7 +348,8 @@ static bool pick_geometry(const dfx_conv_desc &d, MfmaGeom &g, int &lds) {
     for (int tw = (mode == 0 ? d.ow : 32); tw <= (mode == 0 ? d.ow : std::min(d.ow, 256)); tw += 32) {
       if (mode == 1 && tw >= d.ow) break;  // full width is mode 0
       for (int th = 1; th <= std::min(d.oh, th_par); ++th) {
-        const size_t tile = (size_t)(th + 2) * (tw + 2) * d.ic + 16;  // +16: the loader's dump slot
+        // a tile slot holds whole 1 KB pieces (64 granules of 16 bytes: one write per loader lane) + a dump piece
+        const size_t tile = ((size_t)(th + 2) * (tw + 2) * (d.ic / 16) + 63) / 64 * 1024 + 1024;
         if (tile > tile_max) break;
         const int npx = th * tw;
         const int ntiles = mode == 0 ? (npx + 31) / 32 : th * (tw / 32);
@@ -357,7 +358,7 @@ static bool pick_geometry(const dfx_conv_desc &d, MfmaGeom &g, int &lds) {
         // edge units are partial: fraction of the covered area that is real output
         const double cover = ((double)d.oh * d.ow) /
                              ((double)((d.oh + th - 1) / th * th) * ((d.ow + tw - 1) / tw * tw));
-        const bool oversize = (tile - 16) / 16 > (size_t)64 * MFMA_LC;
+        const bool oversize = (tile - 1024) / 16 > (size_t)64 * MFMA_LC;
         double score = px_eff * cover * (0.75 + 0.25 * halo_eff) * (oversize ? 0.9 : 1.0);
         // The 14 compute waves of a CU claim tiles from the units in the 4-slot LDS ring: a unit should
         // bring >= 7 tiles so that two units in flight keep every wave busy while two more are staged
@@ -374,7 +375,7 @@ static bool pick_geometry(const dfx_conv_desc &d, MfmaGeom &g, int &lds) {
   if (const char *e = tune("DFX_FORCE_GEOM")) {  // tuning aid: "th,tw" (must fit LDS)
     int fth = 0, ftw = 0;
     if (sscanf(e, "%d,%d", &fth, &ftw) == 2 && fth >= 1 && (ftw == d.ow || (ftw % 32 == 0 && ftw < d.ow)) &&
-        (size_t)(fth + 2) * (ftw + 2) * d.ic + 16 <= tile_max) {
+        ((size_t)(fth + 2) * (ftw + 2) * (d.ic / 16) + 63) / 64 * 1024 + 1024 <= tile_max) {
       g.th = fth; g.tw = ftw; g.linear = ftw == d.ow;
     }
   }
@@ -384,8 +385,10 @@ static bool pick_geometry(const dfx_conv_desc &d, MfmaGeom &g, int &lds) {
   g.row_chunks = (g.tw + 2) * (d.ic / 16);
   g.tile_chunks = (g.th + 2) * g.row_chunks;
   g.row_magic = (unsigned)(((1ull << 32) + g.row_chunks - 1) / g.row_chunks);
-  g.tile_stride = g.tile_chunks * 16 + 16;
+  g.tile_stride = (g.tile_chunks + 63) / 64 * 1024 + 1024;  // + the loader's dump piece
   g.tw_magic = (unsigned)(((1ull << 32) + g.tw - 1) / g.tw);
+  g.upi_magic = g.uy * g.ux > 1 ? (unsigned)(((1ull << 32) + g.uy * g.ux - 1) / (g.uy * g.ux)) : 0u;
+  g.ux_magic = g.ux > 1 ? (unsigned)(((1ull << 32) + g.ux - 1) / g.ux) : 0u;
   g.ntu = g.linear ? (g.th * g.tw + 31) / 32 : g.th * (g.tw / 32);  // tile claims per unit
   g.ntu_magic = (unsigned)(((1ull << 32) + g.ntu - 1) / g.ntu);
   g.claim_limit = (int)std::min<long long>(0x7ffffff0LL, (long long)g.ntu * ((long long)g.total_units + 4));
@@ -1221,6 +1224,8 @@ int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei, const void *bia0, con
     }
     h->geom.mode0 = mode0;
     h->geom.mode1 = mode1;
+    h->geom.s0_uniform = (fused && d.conv0_nscales == 1) ? 1 : 0;
+    h->geom.s0_value = scales0[0];
   } else {
     memcpy(p0.data(), wei, nw0);
     if (fused) memcpy(p1.data(), wei1, nw1);

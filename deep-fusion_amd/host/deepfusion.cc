@@ -77,7 +77,7 @@ struct memory_state {
 // FNV-1a over 8-byte words (+ tail): the trigger for re-packing borrowed weight tensors.  The
 // reference reads the caller's host buffers on every submit(); here a submit() hashes them
 // (~15 us for the headline op's 53 KB) and re-packs only when the bytes really changed.
-static unsigned long long hash_bytes(const void *p, size_t n, unsigned long long h) {
+inline unsigned long long hash_bytes(const void *p, size_t n, unsigned long long h) {
   const unsigned char *b = static_cast<const unsigned char *>(p);
   size_t i = 0;
   for (; i + 8 <= n; i += 8) {
@@ -91,7 +91,7 @@ static unsigned long long hash_bytes(const void *p, size_t n, unsigned long long
 
 // DEEPFUSION_PROFILE=1 (the env flag the reference reads, util/scaffold.cc:56-82): op::submit()
 // prints "<name> infer <ms>" like the reference's timing wrapper (deepfusion.cc:91-102)
-static bool profiling_enabled() {
+inline bool profiling_enabled() {
   static const bool on = [] {
     const char *e = getenv("DEEPFUSION_PROFILE");
     return e && atoi(e) != 0;
@@ -307,6 +307,7 @@ protected:
     // re-reads them on every call)
     unsigned long long v;
     if (sync_host) {
+      using detail::hash_bytes;
       v = hash_bytes(wei_->host_data(), wei_->buffer_size(), 1469598103934665603ull);
       if (bia_) v = hash_bytes(bia_->host_data(), bia_->buffer_size(), v);
       if (wei1_) v = hash_bytes(wei1_->host_data(), wei1_->buffer_size(), v);

@@ -45,6 +45,9 @@ print("tiles per compute wave: mean %.2f (min %.0f max %.0f); claims per wave: %
 print("start-up (entry -> claim loop): mean %.0f cycles, of which this wave's weight staging (loads + LDS writes) %.0f; rest = barrier wait" % (comp[..., 4].mean(), comp[..., 12].mean()))
 life = comp[..., 9] - comp[..., 8]
 ld = p[:, :, 7, :]
+lu = max(ld[..., 3].sum(), 1.0)
+print("loader waves, per unit staged by the loader itself (%.1f per loader): wait for the slot %.0f cycles, tile write + publish %.0f, next draw + prefetch issue %.0f" % (
+    ld[..., 3].mean(), ld[..., 0].sum() / lu, ld[..., 1].sum() / lu, ld[..., 2].sum() / lu))
 print("loader waves: entry -> barrier %.0f cycles (max %.0f), in the barrier %.0f" % (ld[..., 13].mean(), ld[..., 13].max(), ld[..., 14].mean()))
 print("wave lifetime entry->exit: mean %.0f  min %.0f  max %.0f cycles" % (life.mean(), life.min(), life.max()))
 rt = comp[..., 10]
