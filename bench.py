@@ -156,6 +156,8 @@ def main():
     ap.add_argument("--workload", default="res2a")
     ap.add_argument("--dst", default=None, help="override dst dtype: u8|s8|s32|f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--launch-stats", type=int, default=0,
+                    help="after the timed region, time N more launches one by one and report min/median/p90")
     ap.add_argument("--variant", type=int, default=-1, help="-1 auto, 0 generic, 1/2 resident-weight mfma, 3 streamed-weight mfma")
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="OpenMP threads of the CPU baseline (default: min(host cpus, 16) = one GPU's CPU share)")
@@ -259,6 +261,16 @@ def main():
         elapsed, kern_ms = float(tt[0]), float(tt[1])
 
     extra = {}
+    if args.launch_stats:  # outside the timed region: per-launch durations (their spread, not the mean)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.launch_stats)]
+        for i, (a0, a1) in enumerate(evs):
+            a0.record()
+            op.submit(srcs[i % nbuf], dsts[i % nbuf])
+            a1.record()
+        torch.cuda.synchronize()
+        ds = sorted(a0.elapsed_time(a1) for a0, a1 in evs)
+        extra["launch_ms"] = {"n": len(ds), "min": round(ds[0], 5), "median": round(ds[len(ds) // 2], 5),
+                              "p90": round(ds[int(len(ds) * 0.9)], 5), "max": round(ds[-1], 5)}
     # configs[3]: op_concat + RCCL all-gather, measured outside the timed region
     if world > 1 and dist.get_backend() == "nccl":
         try:

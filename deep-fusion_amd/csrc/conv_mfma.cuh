@@ -68,6 +68,22 @@
 //    (s32/f32) or G-byte (s8/u8) store per lane and a half-wave writes 128*G (or 32*G)
 //    contiguous bytes: whole HBM lines.
 //
+//  * What bounds the kernel (round 2, profiles/stamps.py timelines): the VALU.  A SIMD issues one
+//    wave64 VALU instruction per 4 cycles, and the u8 epilogue needs two instructions per output value
+//    (v_pk_add_f32 + v_pk_mul_f32 on pixel pairs, one v_cvt_pk_u8_f32 per value): 1 k VALU instructions
+//    per 32-pixel tile against 1.7 k cycles of MFMA.  Hence: no per-pixel address arithmetic in vector
+//    registers (scalar pixel bases + one per-lane offset), no int->float conversions (magic start
+//    values), lane-derived values recomputed instead of spilled (a scratch reload waits for every store
+//    in flight), and the scheduling rules below that keep all four SIMDs fed:
+//      - units are split statically and stream-major when a loader gets <= 8 of them, so that every
+//        workgroup processes the same number +-1 (the queue's granularity left 6..8 per workgroup);
+//      - all four ring slots are full when the claim loop starts (compute waves stage units 0/1 with
+//        the weights, each loader its second unit, before the only barrier);
+//      - a wave draws its next claim after conv0 of the current tile and looks at that tile's unit in
+//        the last store group (not a whole tile ahead: parked claims delayed the release of slots);
+//      - a wave that lags behind the other 13 raises its issue priority (the arbiter prefers the
+//        oldest wave of a SIMD; the youngest took 3x as long per tile and held its unit's slot).
+//
 // Round-1 note withdrawn: an earlier revision blamed a one-off wrong output on a hardware
 // hazard (an LDS load overwriting the A/B registers of an MFMA issued just before it).  The
 // isolated probe tools/probe/probe_mfma_war.hip shows no such hazard (0 wrong results in
@@ -88,7 +104,11 @@ constexpr int MFMA_THREADS = 1024;  // 16 waves: 14 compute + 2 loaders (waves 7
 constexpr int MFMA_TEAMS = 2;       // loader waves = unit streams per CU
 constexpr int MFMA_CW = 7;          // compute waves per loader
 constexpr int MFMA_NB = 4;          // input-tile ring slots in LDS (2 per loader)
+#ifndef DFX_STAMPS
 constexpr int MFMA_CTRL_BYTES = 128; // LDS control block, see CTL_* below
+#else
+constexpr int MFMA_CTRL_BYTES = 128 + 16 * 8 * 4; // + the stamps build's per-wave cycle sums ([16 waves][8] ints)
+#endif
 constexpr int MFMA_LC = 22;         // 16-byte chunks the loader wave holds per lane (88 VGPRs)
 constexpr int MFMA_SPIN_LIMIT = 1 << 24;  // bound of every flag wait (~seconds): a protocol error ends the launch
                                           // with wrong output (the parity tests catch it) instead of hanging the GPU
@@ -185,10 +205,27 @@ __device__ __forceinline__ unsigned long long dfx_stamp() {
   return t;
 }
 #define DFX_STAMP(var) const unsigned long long var = dfx_stamp()
-#define DFX_ACC(slot, expr) prof_acc[slot] += (expr)
+// cycle sums live in LDS (behind the control block), not in registers: the kernel sits at the 128-VGPR /
+// ~100-SGPR limit, and register-resident sums made the stamps build spill inside the store loop.
+// All 64 lanes add (the read-out divides by 64).
+#define DFX_ACC(slot, expr) prof_acc[slot] += (expr)  // conv_stream.cuh / conv_direct.cuh: register sums
+// timeline of this wave (stamps build): event n = {v0, v1, v2, v3}; all lanes store the same words
+#define DFX_TLOG(n, v0, v1, v2, v3)                                                                      \
+  do {                                                                                                   \
+    if ((n) < 8) {                                                                                       \
+      unsigned long long *tl_ = g.prof + (size_t)gridDim.x * 256 +                                       \
+                                (((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + (n)) * 4;          \
+      tl_[0] = (v0); tl_[1] = (v1); tl_[2] = (v2); tl_[3] = (v3);                                        \
+    }                                                                                                    \
+  } while (0)
+#define DFX_LACC(slot, expr)                                                                             \
+  __hip_atomic_fetch_add(ctrl + 32 + 8 * (int)(threadIdx.x >> 6) + (slot), (int)(unsigned)(expr), __ATOMIC_RELAXED, \
+                         __HIP_MEMORY_SCOPE_WORKGROUP)
 #else
 #define DFX_STAMP(var)
 #define DFX_ACC(slot, expr)
+#define DFX_LACC(slot, expr)
+#define DFX_TLOG(n, v0, v1, v2, v3)
 #endif
 
 // f32 value of an accumulator before scaling: vcvtdq2ps(acc) + bias, with the
@@ -304,6 +341,14 @@ __device__ __forceinline__ unsigned pack_group(const int (&acc)[G], const float 
 
 // ---- this kernel's store stage.  f[] = one pixel's G consecutive channels after scaling -> ReLU,
 // conversion, one typed store ----
+// sat_u8_bits for the exact-mode code of the resident kernel: the literal is opaque, or hipcc hoists
+// 0xff, 0xff00, ... into VGPRs that stay live across the whole (register-bound) tile loop
+__device__ __forceinline__ unsigned sat_u8_bits_cold(int v) {
+  unsigned lim = 255u;
+  asm volatile("" : "+v"(lim));
+  return min((unsigned)v, lim);
+}
+
 template <int DST, int G, bool FAST>
 __device__ __forceinline__ void store_pixel(unsigned char *p, float (&f)[G], bool relu, int rm) {
   if (DST == DFX_F32) {
@@ -331,7 +376,7 @@ __device__ __forceinline__ void store_pixel(unsigned char *p, float (&f)[G], boo
       } else {
         const float fr = relu ? (FAST ? __builtin_fmaxf(f[c], 0.0f) : relu_x86(f[c])) : f[c];
         const int v = FAST ? (int)__builtin_rintf(fr) : cvt_x86_rt(fr, rm);
-        const unsigned b = (DST == DFX_U8) ? sat_u8_bits(v) : ((unsigned)sat_s8(v) & 0xffu);
+        const unsigned b = (DST == DFX_U8) ? sat_u8_bits_cold(v) : ((unsigned)sat_s8(v) & 0xffu);
         pk |= b << (8 * c);
       }
     }
@@ -378,7 +423,8 @@ __device__ __forceinline__ void emit_pair(unsigned char *p0, unsigned char *p1, 
 // Written as asm because hipcc, given the constant as a v16i splat used by several MFMAs,
 // materialises it in 16 VGPRs per use instead of the inline operand.  hipcc does not look into
 // asm blocks: the wait states it would put between a VALU instruction that writes A / B and the
-// MFMA (it uses 2; tools/probe/probe_mfma_war.hip shows the hazard is real) are in the block.
+// MFMA (it uses 2; that read-after-write dependency is not interlocked: configuration B_valu_raw of
+// tools/probe/probe_mfma_war.hip fails without them) are in the block.
 __device__ __forceinline__ v16i mfma_i8_from_magic(v4i a, v4i b) {
   v16i d;
   asm volatile("s_nop 3\n\tv_mfma_i32_32x32x32_i8 %0, %1, %2, 0.15915494" : "=&v"(d) : "v"(a), "v"(b));
@@ -469,7 +515,15 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
   // published before the barrier: the loader's own start-up (per-lane staging table,
   // 22-chunk prefetch address math) used to sit between the barrier and the first MFMA.
   // The loaders then start with k = 2, 3.  Needs statically known first units.
+  // Stream id of loader `tm` of this workgroup, team-major: a partial last static round (stream ids
+  // below total_units % T) then gives every workgroup one more unit instead of two more to half of them.
+  auto stream_id = [&](int tm) { return tm * (int)gridDim.x + (int)blockIdx.x; };
   const bool coop0 = g.static_rounds >= 1;
+  // coop1: each loader stages its second unit (static as well) into slot 2 + team BEFORE the barrier,
+  // while the compute waves copy the weights: all four slots are full when the claim loop starts.
+  // (Staged after the barrier it was published ~17 k cycles into the loop -- the loader's first pass
+  // through its code is slow -- and half the compute waves sat idle that long: profiles/stamps.py timeline.)
+  const bool coop1 = g.static_rounds >= 2;
 
   // LDS control words are read and written by WHOLE waves (every lane the same word, the same
   // value) and every loaded value goes through readfirstlane, so that all control flow below is
@@ -499,7 +553,7 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
     // first tile of stream `team` (coop0): ring slot `team`, unit blockIdx * 2 + team; its first
     // 4 chunks per thread travel together with the weights (one memory round trip for both)
     unsigned char *slot = tiles + (size_t)team * g.tile_stride;
-    const int unit0 = (int)blockIdx.x * MFMA_TEAMS + team;
+    const int unit0 = stream_id(team);
     const bool tile0 = coop0 && unit0 < g.total_units;
     const uint8_t *src_n = a.src;
     int y0 = 0, x0 = 0;
@@ -547,13 +601,18 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
       int v = 0;
       if (ctid == CTL_END || ctid == CTL_END + 1) {
         v = 0x7fffffff;
-        if (coop0 && (int)blockIdx.x * MFMA_TEAMS + (ctid - CTL_END) >= g.total_units) v = ctid - CTL_END;
+        if (coop0 && stream_id(ctid - CTL_END) >= g.total_units) v = ctid - CTL_END;
       }
-      if (coop0 && (ctid == CTL_FULL || ctid == CTL_FULL + 1) &&
-          (int)blockIdx.x * MFMA_TEAMS + (ctid - CTL_FULL) < g.total_units) v = 1;
-      if (coop0 && ctid >= CTL_INFO && ctid < CTL_INFO + 8) {  // slots 0, 1: the statically owned first units
-        const int u0 = (int)blockIdx.x * MFMA_TEAMS + ((ctid - CTL_INFO) >> 2);
-        if (u0 < g.total_units) {
+      // slot sl starts out published when its unit is staged before the barrier: slots 0, 1 by the
+      // compute waves (coop0), slots 2, 3 by the loaders themselves (coop1: their second unit is static too)
+      auto first_unit = [&](int sl) {
+        const int u = (sl >> 1) * (int)gridDim.x * MFMA_TEAMS + stream_id(sl & 1);
+        return (sl < 2 ? coop0 : coop1) && u < g.total_units ? u : -1;
+      };
+      if (ctid >= CTL_FULL && ctid < CTL_FULL + MFMA_NB && first_unit(ctid - CTL_FULL) >= 0) v = 1;
+      if (ctid >= CTL_INFO && ctid < CTL_INFO + 4 * MFMA_NB) {
+        const int u0 = first_unit((ctid - CTL_INFO) >> 2);
+        if (u0 >= 0) {
           int i0, i1, i2;
           unit_info(u0, i0, i1, i2);
           const int f = (ctid - CTL_INFO) & 3;
@@ -571,7 +630,9 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
     // waves' thousands, but as the youngest waves of their SIMDs they lost every arbitration and
     // needed ~10 k cycles per unit for them (profiles/stamps.py), which left the 14 compute waves
     // waiting for tiles 40 % of the time.
+#ifndef DFX_NO_SETPRIO
     __builtin_amdgcn_s_setprio(3);
+#endif
     v4i pf[MFMA_LC];
     // Per-lane tables for granule lane + 64 i (fixed for the whole launch):
     //   rel[i]   byte offset of its SOURCE chunk from the unit's first halo pixel (tile row 0, column 0)
@@ -641,21 +702,54 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
     // hammering one queue word at kernel start cost ~12 us), the rest come from the
     // device-side queue.  Draws are device-scope atomics that take microseconds to
     // return: one is kept in flight and only broadcast (readfirstlane = wait) when needed.
-    const int T = (int)gridDim.x * MFMA_TEAMS, tg = (int)blockIdx.x * MFMA_TEAMS + team;
+    const int T = (int)gridDim.x * MFMA_TEAMS, tg = stream_id(team);
+    const bool use_queue = g.static_rounds * T < g.total_units;  // false: the static rounds cover the op
     auto unit_at = [&](int j) {
       int v = j * T + tg;
       if (j >= g.static_rounds) {
         v = 0x7fffffff;
-        if (lane == 0) v = g.static_rounds * T + atomicAdd(g.queue, 1);
+        if (use_queue && lane == 0) v = g.static_rounds * T + atomicAdd(g.queue, 1);
       }
       return v;
     };
 
     // coop0: the compute waves stage this stream's first tile themselves; the loader passes
     // the barrier at once (nobody waits for its start-up) and begins with its second unit
+    auto write_tile = [&](unsigned char *ins) {
+      {  // write-late half of the staging: granule lane + 64 i -> LDS byte 16 * (lane + 64 i)
+        // (branch-free: pieces beyond the tile go to the 1 KB dump piece behind it)
+        unsigned char *dst = ins + lane * 16;
+        const int dump = g.tile_stride - 1024;
+#pragma unroll
+        for (int i = 0; i < MFMA_LC; ++i)
+          *reinterpret_cast<v4i *>(dst + (64 * i < g.tile_chunks ? 1024 * i : dump)) = pf[i] ^ x80;
+      }
+      if (cur_fast) {  // padding columns of a fast unit (after the tile writes: same wave, LDS keeps the order)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          if ((padside[m] == 0 && cur_left) || (padside[m] == 1 && cur_right))
+            *reinterpret_cast<v4i *>(ins + padoff[m]) = x80;
+      }
+    };
+    auto write_rest = [&](unsigned char *ins, int unit) {  // oversized tile: the rest is staged synchronously
+      if (g.tile_chunks > 64 * MFMA_LC) {
+        const uint8_t *src_n; int y0, x0;
+        unit_origin(unit, src_n, y0, x0);
+        for (int q = 64 * MFMA_LC + lane; q < g.tile_chunks; q += 64)
+          *reinterpret_cast<v4i *>(ins + 16 * q) = load_granule(src_n, y0, x0, q);
+      }
+    };
     DFX_STAMP(l_pre);
+    int j0 = coop0 ? 1 : 0;
+    if (coop1 && T + tg < g.total_units) {  // (its unit record and FULL flag: see the control block above)
+      const int u1 = T + tg;
+      unsigned char *ins1 = tiles + (size_t)(2 + team) * g.tile_stride;
+      DFX_PREFETCH(u1);
+      write_tile(ins1);
+      write_rest(ins1, u1);
+      j0 = 2;
+    }
     if (coop0) __syncthreads();
-    const int j0 = coop0 ? 1 : 0;
     int cur = __builtin_amdgcn_readfirstlane(unit_at(j0));
     int nxt_v = unit_at(j0 + 1);
     int jn = j0 + 2;
@@ -671,9 +765,6 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
 #endif
 
     DFX_TRACE_AT(100, cur, j0);
-#ifdef DFX_STAMPS
-    unsigned long long lacc[4] = {0, 0, 0, 0};  // slot wait, tile write + publish, next draw + prefetch issue, units
-#endif
     for (int j = j0;; ++j) {
       DFX_STAMP(la);
       const int s = 2 * (j & 1) + team, gen = j >> 1;
@@ -688,26 +779,8 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
       for (int spin = 0; spin < MFMA_SPIN_LIMIT && ctl_load(CTL_DONE + s) < 64 * g.ntu * gen; ++spin)
         __builtin_amdgcn_s_sleep(2);
       DFX_STAMP(lb);
-      {  // write-late half of the staging: granule lane + 64 i -> LDS byte 16 * (lane + 64 i)
-        // (branch-free: pieces beyond the tile go to the 1 KB dump piece behind it)
-        unsigned char *dst = ins + lane * 16;
-        const int dump = g.tile_stride - 1024;
-#pragma unroll
-        for (int i = 0; i < MFMA_LC; ++i)
-          *reinterpret_cast<v4i *>(dst + (64 * i < g.tile_chunks ? 1024 * i : dump)) = pf[i] ^ x80;
-      }
-      if (g.tile_chunks > 64 * MFMA_LC) {  // oversized tile: the rest is staged synchronously
-        const uint8_t *src_n; int y0, x0;
-        unit_origin(cur, src_n, y0, x0);
-        for (int q = 64 * MFMA_LC + lane; q < g.tile_chunks; q += 64)
-          *reinterpret_cast<v4i *>(ins + 16 * q) = load_granule(src_n, y0, x0, q);
-      }
-      if (cur_fast) {  // padding columns of a fast unit (after the tile writes: same wave, LDS keeps the order)
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-          if ((padside[m] == 0 && cur_left) || (padside[m] == 1 && cur_right))
-            *reinterpret_cast<v4i *>(ins + padoff[m]) = x80;
-      }
+      write_tile(ins);
+      write_rest(ins, cur);
       DFX_TRACE_AT(102, cur, j);
       {
         int i0, i1, i2;
@@ -726,13 +799,15 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
       if (cur < g.total_units) DFX_PREFETCH(cur);
       DFX_STAMP(ld);
 #ifdef DFX_STAMPS
-      lacc[0] += lb - la; lacc[1] += lc - lb; lacc[2] += ld - lc; lacc[3] += 1;
+      // slot wait, tile write + publish, next draw + prefetch issue, units
+      DFX_LACC(0, lb - la); DFX_LACC(1, lc - lb); DFX_LACC(2, ld - lc); DFX_LACC(3, 1);
+      DFX_TLOG(j - j0, la - t_entry, lb - t_entry, lc - t_entry, ((unsigned long long)(ld - t_entry) << 16) | (unsigned)(2 * j + team));
 #endif
     }
 #ifdef DFX_STAMPS
     if (lane == 0) {
       unsigned long long *o = g.prof + ((size_t)blockIdx.x * 16 + wave) * 16;
-      o[0] = lacc[0]; o[1] = lacc[1]; o[2] = lacc[2]; o[3] = lacc[3];
+      for (int k = 0; k < 4; ++k) o[k] = (unsigned)ctrl[32 + 8 * wave + k] / 64u;
     }
 #endif
 #undef DFX_PREFETCH
@@ -741,7 +816,7 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
     // could land after the reset.
     DFX_TRACE_AT(103, cur, 0);
     const int pending = __builtin_amdgcn_readfirstlane(nxt_v);
-    if (lane == 0 && pending >= 0) {
+    if (use_queue && lane == 0 && pending >= 0) {
       const int fin = atomicAdd(g.queue + 1, 1);
       if (fin == (int)gridDim.x * MFMA_TEAMS - 1) {
         atomicExch(g.queue, 0);
@@ -770,11 +845,11 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
   const unsigned row_bytes = (unsigned)(FUSED ? OC1 : OC) * ESZ;  // dst bytes per pixel
   const int lds_row = LW * IC;                                    // bytes per halo-tile row in LDS
 
-#ifdef DFX_STAMPS
-  unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
   DFX_STAMP(t_loop);
-  DFX_ACC(4, t_loop - t_entry);  // start-up: weights staging + barrier
+#ifdef DFX_STAMPS
+  int tl_n = 0;
+#endif
+  DFX_LACC(4, t_loop - t_entry);  // start-up: weights staging + barrier
 #ifdef DFX_STAMPS
   const unsigned long long startup_stage = t_staged - t_entry;
 #endif
@@ -782,10 +857,9 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
   // Tile claims.  ds_append returns the counter's old value to the whole wave (wave-uniform) and adds
   // the number of active lanes, 64: claim = old value >> 6.  It is an ordinary LDS instruction with a
   // returned value, so the wait for it sits where the value is first used.  LDS round trips take
-  // ~1 k cycles while 14 waves stream fragments, therefore the control traffic is software-pipelined
-  // two tiles deep: while tile i is computed, the claim of tile i + 2 and the look at the flags and
-  // the unit record of tile i + 1 are in flight.  A claim is always processed by the wave that drew
-  // it (a wave that leaves holds two, both beyond the end).
+  // ~1 k cycles while 14 waves stream fragments, therefore the control traffic of tile i + 1 is issued
+  // inside tile i (see "claim-ahead distance" below).  A claim is always processed by the wave that drew
+  // it (a wave that leaves holds one beyond the end).
   typedef __attribute__((address_space(3))) int lds_int;
   auto draw = [&]() { return __builtin_amdgcn_ds_append((lds_int *)(ctrl + CTL_NEXT)); };
   struct Look { int full, end; v4i info; };
@@ -807,9 +881,13 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
     k = g.ntu == 1 ? t : (int)__umulhi((unsigned)t, g.ntu_magic);  // (ceil(2^32 / 1) does not fit 32 bits)
     ti = t - k * g.ntu;
   };
-  int c_ahead = draw();
-  int t = __builtin_amdgcn_readfirstlane(c_ahead) >> 6, k, ti;
-  c_ahead = draw();
+  // Claim-ahead distance: the NEXT tile's claim is drawn after this tile's conv0 and its flags / unit
+  // record are looked at in the last store group (unfused: claim before conv0, look after it) -- late
+  // enough that a claimed tile does not sit unprocessed for a whole tile time (with only 28 tiles in the
+  // ring, 14 parked claims delayed every slot's release by a round and starved the third round), early
+  // enough to hide the ~1 k-cycle LDS round trips.  The first claim of a wave is synchronous.
+  int c_ahead = 0;
+  int t = __builtin_amdgcn_readfirstlane(draw()) >> 6, k, ti;
   split(t, k, ti);
   Look lk = look(k & (MFMA_NB - 1), k & 1);
   for (;;) {
@@ -825,18 +903,27 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
       __builtin_amdgcn_s_sleep(1);
       lk = look(s, p);
     }
-    // next tile: its claim was drawn one tile ago; look at its unit now, draw the claim after it
     const int t_cur = t, k_cur = k, ti_cur = ti;
     (void)t_cur;
-    t = __builtin_amdgcn_readfirstlane(c_ahead) >> 6;
-    c_ahead = draw();
-    split(t, k, ti);
-    lk = look(k & (MFMA_NB - 1), k & 1);
+    bool drawn = false, looked = false;
+    auto next_draw = [&]() { c_ahead = draw(); drawn = true; };
+    auto next_look = [&]() {
+      t = __builtin_amdgcn_readfirstlane(c_ahead) >> 6;
+      split(t, k, ti);
+      lk = look(k & (MFMA_NB - 1), k & 1);
+      looked = true;
+    };
     DFX_TRACE_AT(5, t_cur, have);
     DFX_STAMP(c1);
-    DFX_ACC(0, c1 - c0);  // wait for the tile's unit (claims and looks are prefetched)
+    DFX_LACC(0, c1 - c0);  // wait for the tile's unit (claims and looks are prefetched)
     if (!have) {  // stream p has no k-th unit; done when the other stream has none for k + 1 either
+#ifdef DFX_STAMPS
+      DFX_TLOG(tl_n, c0 - t_entry, c1 - t_entry, c1 - t_entry, ((unsigned long long)t_cur << 8));
+      ++tl_n;
+#endif
       if (ctl_load(CTL_END + (p ^ 1)) <= k_cur + 1) break;
+      next_draw();
+      next_look();
       continue;
     }
     const int ti_now = ti_cur;
@@ -850,6 +937,12 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
 
     DFX_TRACE_AT(6, pix0, ntiles);
     if (ti_now < ntiles) {
+      // Lane-derived values are recomputed per tile from the lane id (two v_mbcnt, volatile so that it
+      // is not hoisted): kept in registers across the loop they are what hipcc spills, and a
+      // scratch reload waits (vmcnt) for every output store of the previous tile.
+      int lane_t;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_t));
+      const int lane = lane_t, l31 = lane_t & 31, h = lane_t >> 5;
       // pixel of this lane (conv0 column) and the tile's output base (wave-uniform)
       int ty, tx, nvalid;
       size_t obase;  // dst pixel index of px_local == 0
@@ -867,6 +960,7 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
         tx = 32 * tc + min(l31, nvalid - 1);
         obase = (size_t)pix0 + (size_t)tr * a.ow + 32 * tc;
       }
+      nvalid = __builtin_amdgcn_readfirstlane(nvalid);  // wave-uniform: keep it in a scalar register
       // Lane-constant LDS offsets are made opaque once per tile: otherwise LICM
       // hoists every weight / constant fragment read out of the tile loop and
       // keeps >200 VGPRs live across it (spills).
@@ -886,6 +980,7 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
 #pragma unroll
         for (int c = 0; c < ICB; ++c) bb[dx][c] = pb + 16 * ((2 * c + h) ^ sw);
       }
+      if (!FUSED) next_draw();
       v16i acc0[OCB];
       if (FUSED) {  // start values per channel from LDS (0 / comp / bits(1.5 * 2^23) + comp + bias)
 #pragma unroll
@@ -927,6 +1022,7 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
         }
       }
 
+      if (FUSED) next_draw(); else next_look();
       DFX_TRACE_AT(61, 0, 0);
       unsigned char *tile_dst = reinterpret_cast<unsigned char *>(a.dst) + obase * row_bytes;
       using T = std::true_type;
@@ -952,11 +1048,15 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
 #pragma unroll
           for (int e = 0; e < 16; e += 2) {
             const int pl = 8 * (e >> 2) + (e & 3);  // + 4h: pixel of register e; e + 1 is the next pixel
-            const unsigned o0 = decltype(check_tag)::value ? (unsigned)min(pl + h4, nvalid - 1) * row_bytes + ch_off
-                                                           : (unsigned)pl * row_bytes + lane_off;
-            const unsigned o1 = decltype(check_tag)::value ? (unsigned)min(pl + 1 + h4, nvalid - 1) * row_bytes + ch_off
-                                                           : (unsigned)(pl + 1) * row_bytes + lane_off;
-            emit_pair<DST, G, decltype(mode_tag)::value>(tile_dst + o0, tile_dst + o1, acc0, e, ia, fb, fc, relu1, a.rm0);
+            unsigned char *p0, *p1;  // (full tiles: scalar pixel base + one per-lane offset, see the fused stage)
+            if (decltype(check_tag)::value) {
+              p0 = tile_dst + ((unsigned)min(pl + h4, nvalid - 1) * row_bytes + ch_off);
+              p1 = tile_dst + ((unsigned)min(pl + 1 + h4, nvalid - 1) * row_bytes + ch_off);
+            } else {
+              p0 = (tile_dst + (size_t)((unsigned)pl * row_bytes)) + (size_t)lane_off;
+              p1 = (tile_dst + (size_t)((unsigned)(pl + 1) * row_bytes)) + (size_t)lane_off;
+            }
+            emit_pair<DST, G, decltype(mode_tag)::value>(p0, p1, acc0, e, ia, fb, fc, relu1, a.rm0);
           }
         };
         using M0 = std::integral_constant<int, 0>;
@@ -967,7 +1067,7 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
         else { if (nvalid == 32) emit0(M0{}, F{}); else emit0(M0{}, T{}); }
       } else {
       DFX_STAMP(c3);
-      DFX_ACC(1, c3 - c2);  // conv0 MFMA issue
+      DFX_LACC(1, c3 - c2);  // conv0 MFMA issue
       // ---- requant 0 in registers -> A fragments of the 1x1 ----
       v4i mid[OCB];
       if (mode0 == 2 && g.s0_uniform) {  // the same with the op's single scale in scalar registers
@@ -1032,27 +1132,41 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const float f = __fmul_rn(__fadd_rn(__int2float_rn(acc0[r][4 * q + i]), bs[i]), sc[i]);
-              pk |= sat_u8_bits(cvt_x86_rt(relu_x86(f), a.rm0)) << (8 * i);
+              pk |= sat_u8_bits_cold(cvt_x86_rt(relu_x86(f), a.rm0)) << (8 * i);
             }
             mid[r][q] = (int)(pk ^ 0x80808080u);
           }
       }
       DFX_TRACE_AT(62, mode0, mode1);
       DFX_STAMP(c4);
-      DFX_ACC(2, c4 - c3);  // requant 0
+      DFX_LACC(2, c4 - c3);  // requant 0
+      // The claim drawn after conv0 has arrived: move it to a scalar register, the store loop below
+      // needs every VGPR (a spill there makes each tile wait for all of its stores).
+      c_ahead = __builtin_amdgcn_readfirstlane(c_ahead);
+#ifndef DFX_NO_SETPRIO
+      {
+        // Issue priority by how far this wave lags: the SIMD arbiter prefers its oldest wave, so the
+        // youngest of four needed 3x as long per tile (stamps timeline: 12 k vs 33..43 k cycles) -- and a
+        // slot is only refilled when the LAST tile of its unit is done, so the stragglers stalled
+        // everyone.  The distance between this tile's claim and the one just drawn is ~14 when the
+        // wave keeps pace with the other 13.
+        const int lag = (c_ahead >> 6) - t_cur;
+        if (lag > 24) __builtin_amdgcn_s_setprio(3);
+        else if (lag > 18) __builtin_amdgcn_s_setprio(2);
+        else if (lag > 12) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+      }
+#endif
       // ---- conv1 + requant 1 + store, G column blocks at a time ----
       for (int cg = 0; cg < NCG; ++cg) {
+        if (cg == NCG - 1) next_look();
         DFX_TRACE_AT(63, cg, NCG);
+        // (per group from the lane id, itself two v_mbcnt: no live VGPR across the groups instead of three)
+        int lt;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lt));
+        const int lane16 = lt * 16, lch = G * (lt & 31), h4 = 4 * (lt >> 5);
         const int chb = 32 * G * cg + lch;  // this lane's first channel in the group
         v16i acc1[G];
-        int ia[G];
-        v2f fb[G], fc[G];
-#pragma unroll
-        for (int cc = 0; cc < G; ++cc) {
-          ia[cc] = ia1[chb + cc];
-          fb[cc] = pb1[chb + cc];
-          fc[cc] = pc1[chb + cc];
-        }
         v4i wf[OCB][G];
 #pragma unroll
         for (int r = 0; r < OCB; ++r)
@@ -1066,25 +1180,47 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
 #pragma unroll
           for (int cc = 0; cc < G; ++cc)
             acc1[cc] = r == 0 ? mfma_i8_from_magic(mid[0], wf[0][cc]) : mfma_i8(mid[r], wf[r][cc], acc1[cc]);
+        // OCB == 1: every MFMA above is the asm form, whose result hipcc does not know to be an MFMA
+        // result: it would not pad the 12 wait states a VALU read of it needs (probe_mfma_raw).
+        if (OCB == 1) asm volatile("s_nop 7\n\ts_nop 4" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        // requant constants of this lane's channels: fetched behind the MFMAs (their LDS latency
+        // overlaps the matrix pipe; loaded earlier they sit on top of accumulators + weight
+        // fragments, the kernel's register peak)
+        int ia[G];
+        v2f fb[G], fc[G];
+#pragma unroll
+        for (int cc = 0; cc < G; ++cc) {
+          ia[cc] = ia1[chb + cc];
+          fb[cc] = pb1[chb + cc];
+          fc[cc] = pc1[chb + cc];
+        }
         DFX_TRACE_AT(64, cg, nvalid);
         // register e of the accumulator = pixel 8*(e>>2) + 4h + (e&3) of the tile
         // (opaque per group: keeps hipcc from hoisting 16 per-pixel offsets -- of both variants -- out of
         // the group loop and spilling them to scratch)
         unsigned rb = row_bytes;
-        int nv1 = __builtin_amdgcn_readfirstlane(nvalid - 1);
+        int nv1 = nvalid - 1;
         asm volatile("" : "+s"(rb), "+s"(nv1));
-        const unsigned lane_off = (unsigned)h4 * rb + (unsigned)chb * ESZ;
+        const int h4c = h4;
+        const unsigned lane_off = (unsigned)h4c * rb + (unsigned)chb * ESZ;
         const unsigned ch_off = (unsigned)chb * ESZ;
         auto emit = [&](auto mode_tag, auto check_tag) {  // (partial tiles: see the unfused stage above)
 #pragma unroll
           for (int e = 0; e < 16; e += 2) {
             const int pl = 8 * (e >> 2) + (e & 3);  // + 4h: pixel of register e; e + 1 is the next pixel
-            const unsigned o0 = decltype(check_tag)::value ? (unsigned)min(pl + h4, nv1) * rb + ch_off
-                                                           : (unsigned)pl * rb + lane_off;
-            const unsigned o1 = decltype(check_tag)::value ? (unsigned)min(pl + 1 + h4, nv1) * rb + ch_off
-                                                           : (unsigned)(pl + 1) * rb + lane_off;
-            emit_pair<DST, G, decltype(mode_tag)::value>(tile_dst + o0, tile_dst + o1, acc1, e, ia, fb, fc, relu1, a.rm1);
+            // full tiles: scalar pixel base (SALU) + ONE per-lane offset for all 16 stores -- the VALU is
+            // this kernel's bound (4 cycles per wave instruction per SIMD), per-pixel address arithmetic in
+            // vector registers cost a quarter of the epilogue's instructions
+            unsigned char *p0, *p1;
+            if (decltype(check_tag)::value) {
+              p0 = tile_dst + ((unsigned)min(pl + h4c, nv1) * rb + ch_off);
+              p1 = tile_dst + ((unsigned)min(pl + 1 + h4c, nv1) * rb + ch_off);
+            } else {
+              p0 = (tile_dst + (size_t)((unsigned)pl * rb)) + (size_t)lane_off;
+              p1 = (tile_dst + (size_t)((unsigned)(pl + 1) * rb)) + (size_t)lane_off;
+            }
+            emit_pair<DST, G, decltype(mode_tag)::value>(p0, p1, acc1, e, ia, fb, fc, relu1, a.rm1);
           }
         };
         using M0 = std::integral_constant<int, 0>;
@@ -1096,16 +1232,22 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
         DFX_TRACE_AT(66, cg, 0);
       }
       DFX_STAMP(c5);
-      DFX_ACC(3, c5 - c4);  // conv1 + requant 1 + stores
+      DFX_LACC(3, c5 - c4);  // conv1 + requant 1 + stores
       }  // FUSED
-      DFX_ACC(6, 1);
+      DFX_LACC(6, 1);
     }
+    if (!drawn) next_draw();  // (a claim beyond its unit's tiles: nothing was computed)
+    if (!looked) next_look();
     DFX_TRACE_AT(7, t_cur, 0);
     DFX_STAMP(c6);
+#ifdef DFX_STAMPS
+    DFX_TLOG(tl_n, c0 - t_entry, c1 - t_entry, c6 - t_entry, ((unsigned long long)t_cur << 8) | (have ? 1 : 0));
+    ++tl_n;
+#endif
     // count this claim off on its slot (the tile's LDS reads have been consumed by the MFMAs)
     __hip_atomic_fetch_add(ctrl + CTL_DONE + s, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // all 64 lanes: + 64
-    DFX_ACC(5, c6 - c0);  // whole claim
-    DFX_ACC(7, 1);
+    DFX_LACC(5, c6 - c0);  // whole claim
+    DFX_LACC(7, 1);
   }
   DFX_TRACE_AT(9, 0, 0);
 #ifdef DFX_STAMPS
@@ -1115,7 +1257,7 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
     if (lane == 0) {
       unsigned long long *o = g.prof + ((size_t)blockIdx.x * 16 + wave) * 16;
-      for (int k = 0; k < 8; ++k) o[k] = prof_acc[k];
+      for (int k = 0; k < 8; ++k) o[k] = (unsigned)ctrl[32 + 8 * wave + k] / 64u;
       o[8] = t_entry; o[9] = t_end; o[10] = rt; o[11] = rt_entry; o[12] = startup_stage;
     }
   }

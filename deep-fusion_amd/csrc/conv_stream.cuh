@@ -78,14 +78,12 @@ struct StreamGeom {
 #endif
 };
 
-// An LDS load must not target a register that a just-issued MFMA still has to read as
-// A/B operand (see conv_mfma.cuh).  The two fragment sets alternate per k-block and the
-// loads into a set are issued only after >= 2 MFMAs of the OTHER set have been issued
-// since the last MFMA that read it; sched_barrier keeps hipcc from re-mixing the groups.
+// The two fragment sets alternate per k-block; sched_barrier keeps hipcc from hoisting every
+// fragment load of a stage to its top (register pressure) and from re-mixing the groups.
+// (Round 1 read this fence as a workaround for a hardware write-after-read hazard on MFMA A/B
+// operands.  There is none: deep-fusion_amd/tools/probe/probe_mfma_war.hip overwrote the operands
+// 0..32 instructions after 2.6e10 MFMAs without one wrong result -- DESIGN.md section 4.1.)
 #define DFX_FENCE() __builtin_amdgcn_sched_barrier(0)
-#ifndef DFX_EXP
-#define DFX_EXP 0  // timing experiments (profiles/debug/exp_stream.sh): >0 builds produce wrong results
-#endif
 
 template <int OCC, int G, int PXB, int DST, bool FUSED>
 __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, StreamGeom g) {
@@ -133,7 +131,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
     const int off_ = t_ < S0 ? t_ * GA : S0 * GA + (t_ - S0) * GB;                      \
     wmsk = (t_ < S0 ? GA : GB) - 1;                                                     \
     _Pragma("unroll") for (int i = 0; i < NLD; ++i)                                     \
-      if (DFX_EXP != 1) wreg[i] = wsrc[off_ + ((tid + ST_THREADS * i) & wmsk)];         \
+      wreg[i] = wsrc[off_ + ((tid + ST_THREADS * i) & wmsk)];         \
     if (++f_tl == SC) {                                                                 \
       f_tl = 0;                                                                         \
       f_item += (int)gridDim.x;                                                         \
@@ -179,7 +177,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
       const int n_ = min((N0) + img_, a.bs - 1), y_ = min(max(iy_, 0), a.ih - 1);       \
       const int x_ = min(max(ix_, 0), a.iw - 1), c_ = min(cb_, a.ic - 16);              \
       const long long o_ = (((long long)n_ * a.ih + y_) * a.iw + x_) * a.ic + c_;       \
-      if (DFX_EXP != 6) tv[i] = *reinterpret_cast<const v4i *>(a.src + o_);             \
+      tv[i] = *reinterpret_cast<const v4i *>(a.src + o_);             \
       tv_ok = ok_ ? (tv_ok | (1 << i)) : (tv_ok & ~(1 << i));                           \
     }                                                                                   \
   } while (0)
@@ -230,7 +228,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
     DFX_W_FETCH();                                                                      \
   }
 #define DFX_STEP_END()                 \
-  if (DFX_EXP != 5) __syncthreads();   \
+  __syncthreads();   \
   if (++cur == 3) cur = 0
 
   constexpr int NM0 = OCC * PXB, NM1 = G * PXB;  // MFMAs per k-block
@@ -259,8 +257,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
 #define DFX_MFMA0(SET, M0, M1)                                                          \
   _Pragma("unroll") for (int m = (M0); m < (M1); ++m) {                                 \
     const int r = m / PXB, pb = m % PXB;                                                \
-    if (DFX_EXP != 3)                                                                   \
-      acc[pb][r] = FUSED ? mfma_i8(fw[SET][r], fb[SET][pb], acc[pb][r])   /* D0[oc][px] */ \
+    acc[pb][r] = FUSED ? mfma_i8(fw[SET][r], fb[SET][pb], acc[pb][r])   /* D0[oc][px] */ \
                          : mfma_i8(fb[SET][pb], fw[SET][r], acc[pb][r]);  /* D0[px][oc] */ \
   }
 #define DFX_LOAD1(SET, WBI, J)                                                          \
@@ -276,7 +273,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
 #define DFX_MFMA1(SET, M0, M1)                                                          \
   _Pragma("unroll") for (int m = (M0); m < (M1); ++m) {                                 \
     const int cc = m / PXB, pb = m % PXB;                                               \
-    if (DFX_EXP != 3) acc1[pb][cc] = mfma_i8(fb[SET][pb], fw[SET][cc], acc1[pb][cc]);   \
+    acc1[pb][cc] = mfma_i8(fb[SET][pb], fw[SET][cc], acc1[pb][cc]);   \
   }
 
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -476,7 +473,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
             }
             pkv[q] = (int)(pk ^ 0x80808080u);
           }
-          if (DFX_EXP != 2) *reinterpret_cast<v4i *>(my_mid[pb] + (occ * OCC + r) * 32) = pkv;
+          *reinterpret_cast<v4i *>(my_mid[pb] + (occ * OCC + r) * 32) = pkv;
         }
       } else {
         // ---- unfused: typed store; lane owns channels 32*OCC*occ + OCC*l31 + {0..OCC-1} ----
@@ -506,8 +503,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
                 }
               }
           };
-          if (DFX_EXP == 2) { if (acc[0][0][0] == 0x12345678) emit0(TT{}, TT{}); }
-          else if (ESZ == 1 && OCC >= 2 && occ + 1 == occ_hi) { /* staged below: every lane takes part */ }
+          if (ESZ == 1 && OCC >= 2 && occ + 1 == occ_hi) { /* staged below: every lane takes part */ }
           else if (fast) { if (full) emit0(TT{}, FF{}); else emit0(TT{}, TT{}); }
           else      { if (full) emit0(FF{}, FF{}); else emit0(FF{}, TT{}); }
         }
@@ -515,7 +511,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
           // 1-byte outputs, the item's last output chunk (the tile is dead after its K loop:
           // every wave passed the last step's barrier): transpose 32 px x 32*OCC bytes through
           // LDS and write 16 bytes per lane instead of OCC bytes (see the fused stage)
-          if (DFX_EXP != 2 && occ + 1 == occ_hi) {
+          if (occ + 1 == occ_hi) {
             constexpr int RS = 32 * OCC + 16, C16 = 2 * OCC;  // staging row stride; 16-byte chunks per pixel
             unsigned char *stg = tile0 + wave * ST_STAGE;
             unsigned char *dst_b = reinterpret_cast<unsigned char *>(a.dst);
@@ -655,8 +651,7 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
               }
             }
           };
-          if (DFX_EXP == 2) { if (acc1[0][0][0] == 0x12345678) emit1(TT{}, TT{}); }
-          else if (ESZ == 1 && G == 4) { if (fast) emit1s(TT{}); else emit1s(FF{}); }
+          if (ESZ == 1 && G == 4) { if (fast) emit1s(TT{}); else emit1s(FF{}); }
           else if (fast) { if (full) emit1(TT{}, FF{}); else emit1(TT{}, TT{}); }
           else      { if (full) emit1(FF{}, FF{}); else emit1(FF{}, TT{}); }
         }

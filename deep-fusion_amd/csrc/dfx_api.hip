@@ -814,12 +814,21 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     h->geom.mode0 = h->geom.mode1 = 0;
     {
       const int teams = h->grid * MFMA_TEAMS;
-      h->geom.static_rounds = std::min(3, std::max(0, h->geom.total_units / teams - 1));
-      if (const char *e = tune("DFX_STATIC_ROUNDS")) h->geom.static_rounds = std::min(std::max(0, h->geom.total_units / teams - 1), atoi(e));  // tuning aid
+      // Few units per loader (the headline block: 3.5): the queue's granularity -- a whole unit, half a
+      // round of the 14 compute waves -- makes workgroups end up with 6..8 units and the slowest sets the
+      // kernel time (measured spread of workgroup lifetimes: 30 %).  A static split (stream-major, see
+      // stream_id in conv_mfma.cuh) gives every workgroup the same count +- 1 unit.  Many units per
+      // loader: three static rounds, then the queue evens out speed differences between CUs.
+      // (Also for the store-bound s32 headline, whose XCDs finish 40 % apart: static 82.5 us median,
+      // two static rounds + queue 88.5 us, profiles/r02/ab_s32.txt.)
+      const int rounds = (h->geom.total_units + teams - 1) / teams;
+      h->geom.static_rounds = rounds <= 8 ? rounds : 3;
+      if (const char *e = tune("DFX_STATIC_ROUNDS")) h->geom.static_rounds = std::min(rounds, std::max(0, atoi(e)));  // tuning aid
     }
 #ifdef DFX_STAMPS
-    if (hipMalloc((void **)&h->d_prof, (size_t)h->grid * 256 * 8) != hipSuccess ||
-        hipMemset(h->d_prof, 0, (size_t)h->grid * 256 * 8) != hipSuccess) {
+    // [grid][16 waves][16] sums, then [grid][16 waves][8 events][4] timeline words
+    if (hipMalloc((void **)&h->d_prof, (size_t)h->grid * 768 * 8) != hipSuccess ||
+        hipMemset(h->d_prof, 0, (size_t)h->grid * 768 * 8) != hipSuccess) {
       conv_release(h);
       return fail(DFX_ERR_HIP, "conv_create: cannot allocate the stamp buffer");
     }
@@ -1360,7 +1369,7 @@ int *dfx_debug_trace(dfx_conv_t *h) { return h ? h->trace_host : nullptr; }
 // diagnostic build only: copies the [grid][8 waves][8] stamp sums of the last launch
 int dfx_debug_read_stamps(dfx_conv_t *h, unsigned long long *out, int max_entries) {
   if (!h || !h->d_prof) return fail(DFX_ERR_STATE, "no stamps");
-  int n = h->grid * (h->variant == DFX_VARIANT_MFMA_STREAM ? (h->direct ? 64 : 96) : 256);
+  int n = h->grid * (h->variant == DFX_VARIANT_MFMA_STREAM ? (h->direct ? 64 : 96) : 768);
   if (n > max_entries) n = max_entries;
   HIP_TRY(hipMemcpy(out, h->d_prof, (size_t)n * 8, hipMemcpyDeviceToHost));
   return n;

@@ -32,10 +32,11 @@ torch.cuda.synchronize()
 L = capi.lib()
 L.dfx_debug_read_stamps.restype = ctypes.c_int
 L.dfx_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
-buf = np.zeros(info.grid * 256, dtype=np.uint64)
+buf = np.zeros(info.grid * 768, dtype=np.uint64)
 # the kernel overwrites (not accumulates across launches): values are of the last launch
 n = L.dfx_debug_read_stamps(op._h, buf.ctypes.data_as(ctypes.c_void_p), buf.size)
-p = buf[:n].reshape(info.grid, 2, 8, 16).astype(np.float64)
+p = buf[:info.grid * 256].reshape(info.grid, 2, 8, 16).astype(np.float64)
+tl = buf[info.grid * 256:info.grid * 768].reshape(info.grid, 16, 8, 4)
 comp = p[:, :, :7, :]
 print("kernel", info.kernel_name.decode(), "grid", info.grid, "rows/unit", info.rows_per_unit)
 # slots (conv_mfma.cuh, DFX_ACC): 0 claim + wait for the unit's tile, 1 conv0, 2 requant0, 3 conv1 + requant1 + stores,
@@ -68,3 +69,25 @@ wg_life = life.reshape(info.grid, -1).max(axis=1)
 print("per-XCD (blockIdx % 8) mean WG lifetime:", [int(wg_life[x::8].mean()) for x in range(8)])
 q = np.percentile(wg_life, [0, 10, 50, 90, 100])
 print("WG lifetime percentiles 0/10/50/90/100:", [int(v) for v in q])
+
+
+def timeline(cu):
+    """per-wave event log of one workgroup: compute waves (claim start, tile start, tile end, tile id), loaders"""
+    print("-- timeline of workgroup %d (cycles from each wave's kernel entry)" % cu)
+    for w in range(16):
+        ev = tl[cu, w]
+        loader = w in (7, 15)
+        items = []
+        for e in ev:
+            if not e.any():
+                continue
+            if loader:
+                items.append("k%d[wait %d..%d write ..%d prefetch ..%d]" % (int(e[3]) & 0xffff, int(e[0]), int(e[1]), int(e[2]), int(e[3]) >> 16))
+            else:
+                items.append("t%d%s[%d +%d +%d]" % (int(e[3]) >> 8, "" if int(e[3]) & 1 else "x", int(e[0]), int(e[1] - e[0]), int(e[2] - e[1])))
+        print(("L" if loader else "c") + "%02d " % w + " ".join(items))
+
+
+wg_order = np.argsort(wg_life)
+timeline(int(wg_order[len(wg_order) // 2]))
+timeline(int(wg_order[-1]))
