@@ -109,6 +109,31 @@ def cpu_baseline(case, data, threads, gpu_out, budget_s=12.0):
                 if impl == "avx512" else "scalar C, OpenMP over (n,oh)")}
 
 
+def socket_cores():
+    """(physical cores of socket 0, CPUs this process may run on): the second cpu_baseline leg runs on one
+    full socket's physical cores, or on as many as the box lets this process use"""
+    cores = set()
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for l in f:
+                if l.startswith("physical id"):
+                    phys = int(l.split(":")[1])
+                elif l.startswith("core id"):
+                    core = int(l.split(":")[1])
+                elif not l.strip():
+                    if phys == 0 and core is not None:
+                        cores.add(core)
+                    phys = core = None
+    except (OSError, ValueError):
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return (len(cores) or usable), usable
+
+
 def calibrated_peak(hbm_bound):
     """measured roofs of the gpurun MI355X (write stream in the kernel's store shape; back-to-back
     int8 MFMA), see profiles/calibration.json; None if the file is missing"""
@@ -295,6 +320,8 @@ def main():
                        "per_gpu_batch": case.bs, "global_batch": case.bs * world,
                        "parallelism": "batch-sharded x%d, no data-path collective" % world,
                        "kernel": info.kernel_name.decode(), "grid": info.grid,
+                       # two-launch path (3x3 kernel + 1x1 kernel with the intermediate in HBM): not the fused design
+                       "split": info.kernel_name.decode().startswith("split:"),
                        "lds_bytes": info.lds_bytes, "rows_per_unit": info.rows_per_unit},
             "roofline": {"bound": "hbm" if hbm_bound else "mfma",
                          "achieved": round(achieved if hbm_bound else tops, 2),
@@ -314,8 +341,15 @@ def main():
         }
         out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(case, data, args.cpu_threads or min(os.cpu_count() or 1, 16),
-                                               dsts[0][:32].cpu().numpy())
+            gpu_head = dsts[0][:32].cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(case, data, args.cpu_threads or min(os.cpu_count() or 1, 16), gpu_head)
+            # second leg: one full socket's physical cores (or as many as this box lets the process use)
+            sock, usable = socket_cores()
+            n_sock = max(1, min(sock, usable))
+            leg = cpu_baseline(case, data, n_sock, gpu_head, budget_s=8.0)
+            out["cpu_baseline"]["socket"] = {"value": leg["value"], "unit": leg["unit"], "cores": leg["cores"],
+                                             "socket_physical_cores": sock, "usable_cpus": usable,
+                                             "sample": leg["sample"]}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -168,6 +168,7 @@ struct MfmaGeom {  // unit decomposition chosen by the host (dfx_api.hip)
   float s0_value;
   int tile_stride;     // bytes between the MFMA_NB input-tile slots in LDS
   int static_rounds;   // units a loader owns statically before it turns to the queue
+  int lazy_queue;      // 1: a loader draws its next unit only when the slot for it is free (store-bound ops)
   int *queue;          // [0] next unit, [1] finished loaders; both 0 between launches
 #ifdef DFX_STAMPS
   unsigned long long *prof;  // diagnostic build only: [workgroup][wave][16] cycle sums
@@ -523,7 +524,11 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
   // while the compute waves copy the weights: all four slots are full when the claim loop starts.
   // (Staged after the barrier it was published ~17 k cycles into the loop -- the loader's first pass
   // through its code is slow -- and half the compute waves sat idle that long: profiles/stamps.py timeline.)
+#ifdef DFX_EXP_NO_COOP1
+  const bool coop1 = false;
+#else
   const bool coop1 = g.static_rounds >= 2;
+#endif
 
   // LDS control words are read and written by WHOLE waves (every lane the same word, the same
   // value) and every loaded value goes through readfirstlane, so that all control flow below is
@@ -750,10 +755,17 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
       j0 = 2;
     }
     if (coop0) __syncthreads();
-    int cur = __builtin_amdgcn_readfirstlane(unit_at(j0));
-    int nxt_v = unit_at(j0 + 1);
+    // lazy: store-bound ops, whose workgroups run at very different speeds (their share of the HBM write
+    // bandwidth: lifetimes 100 k .. 206 k cycles on the s32 headline).  Drawing ahead -- two units per
+    // loader are staged before the barrier, one more is prefetched, one more drawn -- hands out all 3.5
+    // units per loader in the first quarter of the kernel, so the queue balances nothing.  A lazy loader
+    // draws when the slot for the unit is free: fast workgroups come back for more.  The ~6 us from
+    // draw to published tile are covered by the three other slots (a tile takes ~16 us here).
+    const bool lazy = use_queue && g.lazy_queue;
+    int cur = lazy ? 0 : __builtin_amdgcn_readfirstlane(unit_at(j0));
+    int nxt_v = lazy ? 0 : unit_at(j0 + 1);
     int jn = j0 + 2;
-    if (cur < g.total_units) DFX_PREFETCH(cur);  // (!coop0: the first tile's loads fly during the weight copy)
+    if (!lazy && cur < g.total_units) DFX_PREFETCH(cur);  // (!coop0: the first tile's loads fly during the weight copy)
     if (!coop0) __syncthreads();  // the only workgroup barrier: weights + control block are in LDS
     DFX_STAMP(l_post);
 #ifdef DFX_STAMPS
@@ -770,6 +782,12 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
       const int s = 2 * (j & 1) + team, gen = j >> 1;
       DFX_TRACE_AT(101, cur, j);
       unsigned char *ins = tiles + (size_t)s * g.tile_stride;
+      if (lazy) {  // wait for the slot first, draw (a synchronous device-scope atomic) only then
+        for (int spin = 0; spin < MFMA_SPIN_LIMIT && ctl_load(CTL_DONE + s) < 64 * g.ntu * gen; ++spin)
+          __builtin_amdgcn_s_sleep(8);
+        cur = __builtin_amdgcn_readfirstlane(unit_at(j));
+        if (cur < g.total_units) DFX_PREFETCH(cur);
+      }
       const bool valid = cur < g.total_units;
       if (!valid) {  // this stream has ended at k = 2j + team (a stream that coop0 found empty is marked already)
         if (!(coop0 && j == 1 && tg >= g.total_units)) ctl_store(CTL_END + team, 2 * j + team);
@@ -794,9 +812,11 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // all lanes' tile writes first
       ctl_store(CTL_FULL + s, gen + 1);
       DFX_STAMP(lc);
-      cur = __builtin_amdgcn_readfirstlane(nxt_v);
-      nxt_v = unit_at(jn++);
-      if (cur < g.total_units) DFX_PREFETCH(cur);
+      if (!lazy) {
+        cur = __builtin_amdgcn_readfirstlane(nxt_v);
+        nxt_v = unit_at(jn++);
+        if (cur < g.total_units) DFX_PREFETCH(cur);
+      }
       DFX_STAMP(ld);
 #ifdef DFX_STAMPS
       // slot wait, tile write + publish, next draw + prefetch issue, units
@@ -1217,8 +1237,13 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
               p0 = tile_dst + ((unsigned)min(pl + h4c, nv1) * rb + ch_off);
               p1 = tile_dst + ((unsigned)min(pl + 1 + h4c, nv1) * rb + ch_off);
             } else {
+#ifdef DFX_EXP_VADDR
+              p0 = tile_dst + ((unsigned)pl * rb + lane_off);
+              p1 = tile_dst + ((unsigned)(pl + 1) * rb + lane_off);
+#else
               p0 = (tile_dst + (size_t)((unsigned)pl * rb)) + (size_t)lane_off;
               p1 = (tile_dst + (size_t)((unsigned)(pl + 1) * rb)) + (size_t)lane_off;
+#endif
             }
             emit_pair<DST, G, decltype(mode_tag)::value>(p0, p1, acc1, e, ia, fb, fc, relu1, a.rm1);
           }

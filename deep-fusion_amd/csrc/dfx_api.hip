@@ -89,7 +89,7 @@ static size_t dt_size(int dt) { return (dt == DFX_F32 || dt == DFX_S32) ? 4 : 1;
 // ---- testing / tuning switches.  The environment is read ONCE, when the
 //      library is first used; tests flip a switch afterwards with dfx_debug_set_tuning(). ----
 namespace {
-const char *const kTuningKeys[] = {"DFX_MAX_TH", "DFX_FORCE_GEOM", "DFX_STATIC_ROUNDS", "DFX_NO_FAST", "DFX_NO_MAGIC",
+const char *const kTuningKeys[] = {"DFX_MAX_TH", "DFX_FORCE_GEOM", "DFX_STATIC_ROUNDS", "DFX_NO_FAST", "DFX_NO_MAGIC", "DFX_NO_LAZY",
                                    "DFX_STREAM_PXB", "DFX_STREAM_BLOCKING", "DFX_STREAM_PLANES", "DFX_STREAM_OCC_PAR",
                                    "DFX_STREAM_SPLIT", "DFX_STREAM_DIRECT", "DFX_STREAM_GRID", "DFX_DEBUG_PTRS",
                                    "DEEPFUSION_PROFILE"};
@@ -823,6 +823,14 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
       // two static rounds + queue 88.5 us, profiles/r02/ab_s32.txt.)
       const int rounds = (h->geom.total_units + teams - 1) / teams;
       h->geom.static_rounds = rounds <= 8 ? rounds : 3;
+      // store-bound op (>= 512 output bytes per pixel): two static rounds (staged before the barrier),
+      // then the queue with lazy draws -- see the loader in conv_mfma.cuh
+      const size_t out_px_bytes = (size_t)(d.oc1x1 > 0 ? d.oc1x1 : d.oc) * dt_size(d.dst_dt);
+      h->geom.lazy_queue = 0;
+      if (out_px_bytes >= 512 && rounds > 2 && !tune("DFX_NO_LAZY")) {
+        h->geom.lazy_queue = 1;
+        h->geom.static_rounds = 2;
+      }
       if (const char *e = tune("DFX_STATIC_ROUNDS")) h->geom.static_rounds = std::min(rounds, std::max(0, atoi(e)));  // tuning aid
     }
 #ifdef DFX_STAMPS

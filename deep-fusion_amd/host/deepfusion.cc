@@ -99,6 +99,41 @@ inline bool profiling_enabled() {
   return on;
 }
 
+// Multi-device submit(): DEEPFUSION_DEVICES=<n>|all splits an op's batch into n contiguous shards
+// (the split the reference makes over OpenMP threads, op_conv.cc:155-156 balance211), shard i on
+// visible device i % device_count with its own handle, stream and device buffers.  n may exceed the
+// device count (several shards per device): that is how the sharded path is exercised on a one-GPU
+// box.  Unset or 1: the single-device path.
+inline int requested_shards() {
+  static const int n = [] {
+    const char *e = getenv("DEEPFUSION_DEVICES");
+    if (!e || !*e) return 1;
+    int cnt = 1;
+    if (dfx_device_count(&cnt) != DFX_OK || cnt < 1) cnt = 1;
+    if (!strcmp(e, "all")) return cnt;
+    const int v = atoi(e);
+    return v < 1 ? 1 : v;
+  }();
+  return n;
+}
+struct shard_range { int device, n0, n; };
+inline std::vector<shard_range> plan_shards(int batch) {
+  std::vector<shard_range> v;
+  int want = requested_shards();
+  if (want > batch) want = batch;
+  if (want <= 1) return v;  // empty: single-device path
+  int cnt = 1;
+  if (dfx_device_count(&cnt) != DFX_OK || cnt < 1) cnt = 1;
+  const int base = batch / want, rem = batch % want;
+  int n0 = 0;
+  for (int i = 0; i < want; ++i) {
+    const int n = base + (i < rem ? 1 : 0);
+    v.push_back({i % cnt, n0, n});
+    n0 += n;
+  }
+  return v;
+}
+
 // shared plumbing of the two ops: access to the tensors' private state
 struct op_state {
   dfx_stream_t stream = nullptr;
@@ -154,6 +189,8 @@ struct op_state {
     check_dfx(dfx_memcpy_d2h(s->host, s->device, s->bytes, stream), "D2H copy");
     s->uploaded_version = s->host_version;  // host == device after the copy
   }
+  // sharded submit wrote m's HOST buffer directly: any device copy is stale
+  static void host_is_current(memory &m) { m.st_->uploaded_version = 0; m.st_->producer = nullptr; }
   ~op_state() {
     if (ev0) dfx_event_destroy(ev0);
     if (ev1) dfx_event_destroy(ev1);
@@ -284,21 +321,104 @@ public:
     d.conv0_nscales = (int)scales0_.size();
     d.conv1_nscales = wei1_ ? (int)scales1_.size() : 1;
     d.force_variant = -1;
+    const size_t src_img = (size_t)d.ih * d.iw * d.ic;
+    const size_t dst_img = (size_t)d.oh * d.ow * (d.oc1x1 ? d.oc1x1 : d.oc) * dtype_size(dst_->data_type());
+    for (const detail::shard_range &r : detail::plan_shards(d.bs)) {
+      shard sh;
+      sh.r = r;
+      sh.src_off = r.n0 * src_img; sh.src_bytes = r.n * src_img;
+      sh.dst_off = r.n0 * dst_img; sh.dst_bytes = r.n * dst_img;
+      dfx_conv_desc ds = d;
+      ds.bs = r.n;
+      check_dfx(dfx_set_device(r.device), "set device");
+      if (dfx_conv_create(&ds, &sh.h) != DFX_OK) error_and_exit("Init Conv op failed! (%s)", dfx_last_error());
+      check_dfx(dfx_stream_create(&sh.stream), "stream create");
+      check_dfx(dfx_mem_alloc_device(&sh.src, sh.src_bytes), "device alloc");
+      check_dfx(dfx_mem_alloc_device(&sh.dst, sh.dst_bytes), "device alloc");
+      shards_.push_back(sh);
+    }
+    if (!shards_.empty()) {
+      check_dfx(dfx_set_device(shards_[0].r.device), "set device");
+      return;
+    }
     if (dfx_conv_create(&d, &h_) != DFX_OK) error_and_exit("Init Conv op failed! (%s)", dfx_last_error());
     st_.ensure_stream();
   }
-  ~op_conv() override { dfx_conv_destroy(h_); }
+  ~op_conv() override {
+    for (shard &sh : shards_) {
+      dfx_set_device(sh.r.device);
+      dfx_conv_destroy(sh.h);
+      dfx_stream_destroy(sh.stream);
+      dfx_mem_free_device(sh.src);
+      dfx_mem_free_device(sh.dst);
+    }
+    if (!shards_.empty()) dfx_set_device(shards_[0].r.device);
+    dfx_conv_destroy(h_);
+  }
 
   void submit() override {
+    if (!shards_.empty()) {
+      enqueue_shards();
+      sync_shards();
+      return;
+    }
     run(true);
     st_.fetch_out(*dst_);
     check_dfx(dfx_stream_sync(st_.stream), "stream sync");
   }
-  void submit_async() override { run(false); }
-  void wait() override { check_dfx(dfx_stream_sync(st_.stream), "stream sync"); }
+  // (sharded: host in -> host out like submit(), without the final wait; the device-resident
+  // chaining extension is single-device)
+  void submit_async() override {
+    if (!shards_.empty()) enqueue_shards();
+    else run(false);
+  }
+  void wait() override {
+    if (!shards_.empty()) sync_shards();
+    else check_dfx(dfx_stream_sync(st_.stream), "stream sync");
+  }
 
 protected:
-  void infer() override { run(true); }
+  void infer() override {
+    if (!shards_.empty()) enqueue_shards();
+    else run(true);
+  }
+  unsigned long long weights_hash() {
+    using detail::hash_bytes;
+    unsigned long long v = hash_bytes(wei_->host_data(), wei_->buffer_size(), 1469598103934665603ull);
+    if (bia_) v = hash_bytes(bia_->host_data(), bia_->buffer_size(), v);
+    if (wei1_) v = hash_bytes(wei1_->host_data(), wei1_->buffer_size(), v);
+    if (bia1_) v = hash_bytes(bia1_->host_data(), bia1_->buffer_size(), v);
+    return v | 1ull << 63;  // (never equal to a version sum)
+  }
+  // every shard: upload its images from the host tensor, launch, download into the host tensor
+  void enqueue_shards() {
+    const unsigned long long v = weights_hash();
+    const char *hs = static_cast<const char *>(src_->host_data());
+    char *hd = static_cast<char *>(const_cast<void *>(dst_->host_data()));
+    for (shard &sh : shards_) {
+      check_dfx(dfx_set_device(sh.r.device), "set device");
+      if (v != sh.wei_seen) {
+        check_dfx(dfx_stream_sync(sh.stream), "stream sync");
+        check_dfx(dfx_conv_set_weights(sh.h, (const int8_t *)wei_->host_data(), bia_ ? bia_->host_data() : nullptr,
+                                       scales0_.data(), wei1_ ? (const int8_t *)wei1_->host_data() : nullptr,
+                                       bia1_ ? bia1_->host_data() : nullptr, scales1_.data()),
+                  "conv set_weights");
+        sh.wei_seen = v;
+      }
+      check_dfx(dfx_memcpy_h2d(sh.src, hs + sh.src_off, sh.src_bytes, sh.stream), "H2D copy");
+      check_dfx(dfx_conv_submit(sh.h, sh.src, sh.dst, sh.stream), "conv submit");
+      check_dfx(dfx_memcpy_d2h(hd + sh.dst_off, sh.dst, sh.dst_bytes, sh.stream), "D2H copy");
+    }
+    check_dfx(dfx_set_device(shards_[0].r.device), "set device");
+    detail::op_state::host_is_current(*dst_);
+  }
+  void sync_shards() {
+    for (shard &sh : shards_) {
+      check_dfx(dfx_set_device(sh.r.device), "set device");
+      check_dfx(dfx_stream_sync(sh.stream), "stream sync");
+    }
+    check_dfx(dfx_set_device(shards_[0].r.device), "set device");
+  }
   // sync_host == true: reference semantics (host buffers are re-read: inputs uploaded, weights
   // re-packed when their bytes changed).  false: the asynchronous device-resident extension,
   // which trusts the data() version counters.
@@ -307,12 +427,7 @@ protected:
     // re-reads them on every call)
     unsigned long long v;
     if (sync_host) {
-      using detail::hash_bytes;
-      v = hash_bytes(wei_->host_data(), wei_->buffer_size(), 1469598103934665603ull);
-      if (bia_) v = hash_bytes(bia_->host_data(), bia_->buffer_size(), v);
-      if (wei1_) v = hash_bytes(wei1_->host_data(), wei1_->buffer_size(), v);
-      if (bia1_) v = hash_bytes(bia1_->host_data(), bia1_->buffer_size(), v);
-      v |= 1ull << 63;  // (never equal to a version sum)
+      v = weights_hash();
     } else {
       v = wei_->host_version() + (bia_ ? bia_->host_version() : 0) +
           (wei1_ ? wei1_->host_version() : 0) + (bia1_ ? bia1_->host_version() : 0);
@@ -336,11 +451,20 @@ protected:
   const char *name() override { return "conv"; }
 
 private:
+  struct shard {
+    detail::shard_range r;
+    dfx_conv_t *h = nullptr;
+    dfx_stream_t stream = nullptr;
+    void *src = nullptr, *dst = nullptr;
+    size_t src_off = 0, src_bytes = 0, dst_off = 0, dst_bytes = 0;
+    unsigned long long wei_seen = 0;
+  };
   memory *src_, *wei_, *bia_, *wei1_, *bia1_, *dst_;
   std::vector<float> scales0_, scales1_;  // owned copies (the reference keeps a dangling pointer)
   dfx_conv_t *h_;
   unsigned long long wei_seen_;
   detail::op_state st_;
+  std::vector<shard> shards_;  // DEEPFUSION_DEVICES > 1: one entry per batch shard; empty otherwise
 };
 
 // ---- concat: replaces op_concat<T> ----
@@ -370,21 +494,91 @@ public:
     d.dt = to_dfx_dtype(dst_->data_type());
     d.post_relu = relu;
     d.channels = ch.data();
+    const size_t esz = dtype_size(dst_->data_type()), px = (size_t)dm[1] * dm[2];
+    for (const detail::shard_range &r : detail::plan_shards(d.bs)) {
+      shard sh;
+      sh.r = r;
+      dfx_concat_desc ds = d;
+      ds.bs = r.n;
+      check_dfx(dfx_set_device(r.device), "set device");
+      if (dfx_concat_create(&ds, &sh.h) != DFX_OK) error_and_exit("Init Concat op failed! (%s)", dfx_last_error());
+      check_dfx(dfx_stream_create(&sh.stream), "stream create");
+      for (int c : ch) {
+        void *p = nullptr;
+        check_dfx(dfx_mem_alloc_device(&p, (size_t)r.n * px * c * esz), "device alloc");
+        sh.srcs.push_back(p);
+        sh.src_img.push_back(px * c * esz);
+      }
+      sh.dst_img = px * total * esz;
+      check_dfx(dfx_mem_alloc_device(&sh.dst, (size_t)r.n * sh.dst_img), "device alloc");
+      shards_.push_back(sh);
+    }
+    if (!shards_.empty()) {
+      check_dfx(dfx_set_device(shards_[0].r.device), "set device");
+      return;
+    }
     if (dfx_concat_create(&d, &h_) != DFX_OK) error_and_exit("Init Concat op failed! (%s)", dfx_last_error());
     st_.ensure_stream();
   }
-  ~op_concat() override { dfx_concat_destroy(h_); }
+  ~op_concat() override {
+    for (shard &sh : shards_) {
+      dfx_set_device(sh.r.device);
+      dfx_concat_destroy(sh.h);
+      dfx_stream_destroy(sh.stream);
+      for (void *p : sh.srcs) dfx_mem_free_device(p);
+      dfx_mem_free_device(sh.dst);
+    }
+    if (!shards_.empty()) dfx_set_device(shards_[0].r.device);
+    dfx_concat_destroy(h_);
+  }
 
   void submit() override {
+    if (!shards_.empty()) {
+      enqueue_shards();
+      sync_shards();
+      return;
+    }
     run(true);
     st_.fetch_out(*dst_);
     check_dfx(dfx_stream_sync(st_.stream), "stream sync");
   }
-  void submit_async() override { run(false); }
-  void wait() override { check_dfx(dfx_stream_sync(st_.stream), "stream sync"); }
+  void submit_async() override {
+    if (!shards_.empty()) enqueue_shards();
+    else run(false);
+  }
+  void wait() override {
+    if (!shards_.empty()) sync_shards();
+    else check_dfx(dfx_stream_sync(st_.stream), "stream sync");
+  }
 
 protected:
-  void infer() override { run(true); }
+  void infer() override {
+    if (!shards_.empty()) enqueue_shards();
+    else run(true);
+  }
+  void enqueue_shards() {  // (see op_conv: host in -> host out per batch shard)
+    char *hd = static_cast<char *>(const_cast<void *>(dst_->host_data()));
+    for (shard &sh : shards_) {
+      check_dfx(dfx_set_device(sh.r.device), "set device");
+      std::vector<const void *> p;
+      for (size_t k = 0; k < srcs_.size(); ++k) {
+        const char *hs = static_cast<const char *>(srcs_[k]->host_data());
+        check_dfx(dfx_memcpy_h2d(sh.srcs[k], hs + sh.r.n0 * sh.src_img[k], sh.r.n * sh.src_img[k], sh.stream), "H2D copy");
+        p.push_back(sh.srcs[k]);
+      }
+      check_dfx(dfx_concat_submit(sh.h, p.data(), sh.dst, sh.stream), "concat submit");
+      check_dfx(dfx_memcpy_d2h(hd + sh.r.n0 * sh.dst_img, sh.dst, sh.r.n * sh.dst_img, sh.stream), "D2H copy");
+    }
+    check_dfx(dfx_set_device(shards_[0].r.device), "set device");
+    detail::op_state::host_is_current(*dst_);
+  }
+  void sync_shards() {
+    for (shard &sh : shards_) {
+      check_dfx(dfx_set_device(sh.r.device), "set device");
+      check_dfx(dfx_stream_sync(sh.stream), "stream sync");
+    }
+    check_dfx(dfx_set_device(shards_[0].r.device), "set device");
+  }
   void run(bool sync_host) {
     std::vector<const void *> p;
     for (memory *m : srcs_) p.push_back(st_.sync_in(*m, sync_host));
@@ -396,10 +590,20 @@ protected:
   const char *name() override { return "concat"; }
 
 private:
+  struct shard {
+    detail::shard_range r;
+    dfx_concat_t *h = nullptr;
+    dfx_stream_t stream = nullptr;
+    std::vector<void *> srcs;
+    std::vector<size_t> src_img;  // bytes per image of each input
+    void *dst = nullptr;
+    size_t dst_img = 0;
+  };
   std::vector<memory *> srcs_;
   memory *dst_;
   dfx_concat_t *h_;
   detail::op_state st_;
+  std::vector<shard> shards_;  // DEEPFUSION_DEVICES > 1 (see op_conv)
 };
 
 }  // namespace

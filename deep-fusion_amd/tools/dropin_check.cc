@@ -55,6 +55,35 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < src->size(); ++i) ((uint8_t *)src->data())[i] = (uint8_t)(16 - s[i]);
     c->submit();
     dump(out + "/fused_dst2.bin", dst->data(), dst->buffer_size());
+    // ... and so must a refill through the pointer `s` fetched once, before the first submit (the
+    // reference reads host memory on every submit; the usual inference loop caches the pointer)
+    for (size_t i = 0; i < src->size(); ++i) s[i] = (uint8_t)((i * 7 + 3) % 17);
+    c->submit();
+    dump(out + "/fused_src3.bin", src->host_data(), src->buffer_size());
+    dump(out + "/fused_dst3.bin", dst->host_data(), dst->buffer_size());
+  }
+  // ---- fused conv, N=5 (uneven over 2 or 3 batch shards: DEEPFUSION_DEVICES), s32 out ----
+  {
+    const int bs = 5, ic = 32, ih = 9, iw = 11, oc = 32, oc1 = 32;
+    std::unique_ptr<memory> src(new memory(memory::nchw_dims{bs, ic, ih, iw}, memory::format::nhwc, memory::dtype::u8));
+    std::unique_ptr<memory> wei(new memory(memory::nchw_dims{oc, ic, 3, 3}, memory::format::OIhw4i16o4i, memory::dtype::s8));
+    std::unique_ptr<memory> wei1(new memory(memory::nchw_dims{oc1, oc, 1, 1}, memory::format::OIhw4i16o4i, memory::dtype::s8));
+    std::unique_ptr<memory> dst(new memory(memory::nchw_dims{bs, oc1, ih, iw}, memory::format::nhwc, memory::dtype::s32));
+    uint8_t *s = (uint8_t *)src->data();
+    for (size_t i = 0; i < src->size(); ++i) s[i] = (uint8_t)(g.next() % 256);
+    std::vector<s8> w0(wei->size()), w1(wei1->size());
+    for (auto &v : w0) v = (s8)((int)(g.next() % 31) - 15);
+    for (auto &v : w1) v = (s8)((int)(g.next() % 31) - 15);
+    reorder_weights(w0.data(), wei);
+    reorder_weights(w1.data(), wei1);
+    static const std::unique_ptr<memory> none;
+    auto c = conv(src, wei, none, {1, 1}, {1, 1}, wei1, none, dst, true, {1.f / 256}, round_mode::nearest, false, {1.f / 8},
+                  round_mode::nearest);
+    c->submit();
+    dump(out + "/n5_src.bin", src->host_data(), src->buffer_size());
+    dump(out + "/n5_w0_oihw.bin", w0.data(), w0.size());
+    dump(out + "/n5_w1_oihw.bin", w1.data(), w1.size());
+    dump(out + "/n5_dst.bin", dst->data(), dst->buffer_size());
   }
   // ---- unfused conv: N=1, 9x7, 32 -> 48, stride 2, pad 1, s8 out, no relu, round down ----
   {

@@ -42,6 +42,17 @@ def test_dropin_cpp_api(oracle, tmp_path):
     got2 = _load(d, "fused_dst2.bin", np.uint8, (2, 13, 13, 64))       # input rewritten via data()
     assert np.array_equal(got2, ref_fused((16 - src.astype(np.int32)).astype(np.uint8)))
     assert not np.array_equal(got, got2)
+    src3 = _load(d, "fused_src3.bin", np.uint8, (2, 13, 13, 32))       # refilled through a cached pointer
+    assert np.array_equal(_load(d, "fused_dst3.bin", np.uint8, (2, 13, 13, 64)), ref_fused(src3))
+    assert not np.array_equal(src3, src)
+    # fused conv N=5, s32 out, no bias
+    s5 = _load(d, "n5_src.bin", np.uint8, (5, 9, 11, 32))
+    w50 = _load(d, "n5_w0_oihw.bin", np.int8, (32, 32, 3, 3))
+    w51 = _load(d, "n5_w1_oihw.bin", np.int8, (32, 32, 1, 1))
+    ref5 = oracle.conv(s5, oracle.reorder_oihw_to_blocked(w50), w50.shape, (1, 1), (1, 1), C.S32,
+                       np.array([1.0 / 256], dtype=np.float32), wei1_blk=oracle.reorder_oihw_to_blocked(w51),
+                       oc1x1=32, scales1=np.array([1.0 / 8], dtype=np.float32), relu0=True, relu1=False)
+    assert np.array_equal(_load(d, "n5_dst.bin", np.int32, ref5.shape), ref5)
     # unfused conv, stride 2, s8 out, round down
     src = _load(d, "unfused_src.bin", np.uint8, (1, 9, 7, 32))
     w0 = _load(d, "unfused_w0_oihw.bin", np.int8, (48, 32, 3, 3))
@@ -74,3 +85,21 @@ def test_init_failure_exits_like_reference(tmp_path):
     r = subprocess.run([os.path.join(TOOLS, "bench_conv"), "-bs", "1", "-ih", "8", "-iw", "8", "-ic", "24", "-oc", "32",
                         "-oc1x1", "32", "-burning_iter", "0", "-iter", "1"], capture_output=True)
     assert r.returncode == 1 and b"[deepfusion]" in r.stderr and b"failed" in r.stderr
+
+
+@pytest.mark.parametrize("shards", ["2", "3", "all"])
+def test_dropin_multi_device_same_bytes(tmp_path, shards):
+    """DEEPFUSION_DEVICES=n: the drop-in layer splits each op's batch over n shards (device i % count,
+    own handle / stream / buffers per shard).  Every output file must equal the single-device run's
+    byte for byte -- on a one-GPU box the shards share the device, on an N-GPU node they spread."""
+    exe = os.path.join(TOOLS, "dropin_check")
+    one, many = tmp_path / "one", tmp_path / "many"
+    one.mkdir()
+    many.mkdir()
+    env = {k: v for k, v in os.environ.items() if k != "DEEPFUSION_DEVICES"}
+    subprocess.check_call([exe, str(one)], env=env)
+    subprocess.check_call([exe, str(many)], env=dict(env, DEEPFUSION_DEVICES=shards))
+    names = sorted(os.listdir(str(one)))
+    assert names == sorted(os.listdir(str(many))) and any("dst" in n for n in names)
+    for n in names:
+        assert (one / n).read_bytes() == (many / n).read_bytes(), n
