@@ -363,8 +363,16 @@ static bool pick_geometry(const dfx_conv_desc &d, MfmaGeom &g, int &lds) {
         // The 14 compute waves of a CU claim tiles from the units in the 4-slot LDS ring: a unit should
         // bring >= 7 tiles so that two units in flight keep every wave busy while two more are staged
         // (measured at config 3, s32: 2-row units of 4 tiles 124 us, 4-row units of 7 tiles 97 us)
-        score *= 0.5 + 0.5 * std::min(1.0, ntiles / 7.0);
-        (void)hbm_bound_dst;
+        const bool store_bound = hbm_bound_dst && (size_t)(d.oc1x1 > 0 ? d.oc1x1 : d.oc) * 4 >= 512;
+        score *= 0.5 + 0.5 * std::min(1.0, ntiles / (store_bound ? 4.0 : 7.0));
+        // Store-bound ops (>= 512 output bytes per pixel): workgroups drain at very different rates and
+        // the lazy queue (conv_mfma.cuh) can only even that out with enough units per loader -- >= 6
+        // (s32 headline, same box: 2-row units / 7 per loader 84.1 us, 4-row units / 3.5 per loader 86.5 us)
+        if (store_bound) {
+          if (mode == 1) score *= 0.9;  // column-split units end in partial tiles (the slower store form)
+          const double units = (double)d.bs * ((d.oh + th - 1) / th) * ((d.ow + tw - 1) / tw);
+          score *= 0.5 + 0.5 * std::min(1.0, units / (6.0 * 512.0));
+        }
         if (score > best) {
           best = score;
           g.th = th; g.tw = tw; g.linear = mode == 0;
