@@ -114,6 +114,34 @@ def test_resident_kernel_requant_modes(hip, oracle, tuning, case, switch):
     hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), info.kernel_name.decode() + " " + switch)
 
 
+SCHED_CASES = [
+    # >= 3 rounds of units per loader at 2-row units: static split, lazy queue, eager queue all apply
+    C.ConvCase("sched_s32", 80, 64, 56, 56, 64, 256, dst_dt=C.S32),
+    C.ConvCase("sched_u8", 80, 64, 56, 56, 64, 256, dst_dt=C.U8),
+    # many units per loader (three static rounds, then the queue), partial last round
+    C.ConvCase("sched_f32", 9, 32, 120, 200, 64, 0, dst_dt=C.F32),
+]
+
+
+@pytest.mark.parametrize("case", SCHED_CASES, ids=lambda c: c.ident())
+def test_resident_kernel_unit_scheduling(hip, oracle, tuning, case):
+    """how units reach the loaders (conv_mfma.cuh: static stream-major split, lazy queue draws for
+    store-bound ops, eager queue) must not change a byte: every mode is compared with the default
+    run, and the default run's first images with the oracle."""
+    data = C.generate(case)
+    ref_run, info = hip.hip_conv(case, data)
+    assert info.variant in (hip.dfa.VARIANT_MFMA_FUSED, hip.dfa.VARIANT_MFMA_CONV), info.kernel_name
+    n = min(case.bs, 6)
+    sub = dict(data, src=data["src"][:n])
+    hip.assert_bit_equal(ref_run[:n], hip.oracle_conv(oracle, replace(case, bs=n), sub), info.kernel_name.decode())
+    for key, val in (("DFX_NO_LAZY", "1"), ("DFX_STATIC_ROUNDS", "1"), ("DFX_STATIC_ROUNDS", "2"),
+                     ("DFX_STATIC_ROUNDS", "99"), ("DFX_FORCE_GEOM", "4,56" if case.iw == 56 else "3,32")):
+        tuning.setenv(key, val)
+        got, _ = hip.hip_conv(case, data)
+        tuning.undo()
+        assert np.array_equal(got, ref_run), "%s=%s changes the result" % (key, val)
+
+
 # streamed-weight MFMA variant (conv_stream.cuh): general shapes -- SURVEY.md 8(f) rank 3
 STREAM_SHAPES = [
     C.ConvCase("s2", 1, 16, 11, 9, 48, 80, stride=(2, 2)),
