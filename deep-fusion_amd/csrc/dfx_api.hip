@@ -89,7 +89,7 @@ static size_t dt_size(int dt) { return (dt == DFX_F32 || dt == DFX_S32) ? 4 : 1;
 // ---- testing / tuning switches.  The environment is read ONCE, when the
 //      library is first used; tests flip a switch afterwards with dfx_debug_set_tuning(). ----
 namespace {
-const char *const kTuningKeys[] = {"DFX_MAX_TH", "DFX_FORCE_GEOM", "DFX_STATIC_ROUNDS", "DFX_NO_FAST", "DFX_NO_MAGIC", "DFX_NO_LAZY",
+const char *const kTuningKeys[] = {"DFX_MAX_TH", "DFX_FORCE_GEOM", "DFX_STATIC_ROUNDS", "DFX_NO_FAST", "DFX_NO_MAGIC", "DFX_NO_LAZY", "DFX_STORE_BOUND_BYTES",
                                    "DFX_STREAM_PXB", "DFX_STREAM_BLOCKING", "DFX_STREAM_PLANES", "DFX_STREAM_OCC_PAR",
                                    "DFX_STREAM_SPLIT", "DFX_STREAM_DIRECT", "DFX_STREAM_GRID", "DFX_DEBUG_PTRS",
                                    "DEEPFUSION_PROFILE"};
@@ -329,6 +329,12 @@ static size_t round16(size_t v) { return (v + 15) & ~(size_t)15; }
 // little halo it re-reads, whether the loader wave can hold the whole halo tile in
 // registers, and -- for HBM-bound outputs -- how fine the dynamic hand-out is.
 // false if nothing fits LDS.
+// output bytes per pixel from which an op counts as bound by its output stream (finer units, lazy queue)
+static size_t store_bound_bytes() {
+  if (const char *e = tune("DFX_STORE_BOUND_BYTES")) return (size_t)std::max(1, atoi(e));  // tuning aid
+  return 512;
+}
+
 static bool pick_geometry(const dfx_conv_desc &d, MfmaGeom &g, int &lds) {
   const int ICB = d.ic / 32, OCB = d.oc / 32, NCB = d.oc1x1 / 32;
   const size_t fixed = (size_t)OCB * 9 * ICB * 1024 + (size_t)NCB * OCB * 1024 +
@@ -363,7 +369,7 @@ static bool pick_geometry(const dfx_conv_desc &d, MfmaGeom &g, int &lds) {
         // The 14 compute waves of a CU claim tiles from the units in the 4-slot LDS ring: a unit should
         // bring >= 7 tiles so that two units in flight keep every wave busy while two more are staged
         // (measured at config 3, s32: 2-row units of 4 tiles 124 us, 4-row units of 7 tiles 97 us)
-        const bool store_bound = hbm_bound_dst && (size_t)(d.oc1x1 > 0 ? d.oc1x1 : d.oc) * 4 >= 512;
+        const bool store_bound = hbm_bound_dst && (size_t)(d.oc1x1 > 0 ? d.oc1x1 : d.oc) * 4 >= store_bound_bytes();
         score *= 0.5 + 0.5 * std::min(1.0, ntiles / (store_bound ? 4.0 : 7.0));
         // Store-bound ops (>= 512 output bytes per pixel): workgroups drain at very different rates and
         // the lazy queue (conv_mfma.cuh) can only even that out with enough units per loader -- >= 6
@@ -835,7 +841,7 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
       // then the queue with lazy draws -- see the loader in conv_mfma.cuh
       const size_t out_px_bytes = (size_t)(d.oc1x1 > 0 ? d.oc1x1 : d.oc) * dt_size(d.dst_dt);
       h->geom.lazy_queue = 0;
-      if (out_px_bytes >= 512 && rounds > 2 && !tune("DFX_NO_LAZY")) {
+      if (out_px_bytes >= store_bound_bytes() && rounds > 2 && !tune("DFX_NO_LAZY")) {
         h->geom.lazy_queue = 1;
         h->geom.static_rounds = 2;
       }
