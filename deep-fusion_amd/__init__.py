@@ -12,6 +12,6 @@ carries a hyphen).
 """
 from .capi import (  # noqa: F401
     DFX_F32, DFX_S32, DFX_S8, DFX_U8, DFX_UNDEF, ROUND_NEAREST, ROUND_DOWN,
-    VARIANT_GENERIC, VARIANT_MFMA_FUSED, VARIANT_MFMA_CONV, VARIANT_MFMA_STREAM, DfxError, ConvDesc, ConvInfo, Conv, Concat,
+    VARIANT_GENERIC, VARIANT_MFMA_FUSED, VARIANT_MFMA_CONV, VARIANT_MFMA_STREAM, DfxError, ConvDesc, ConvInfo, Conv, Concat, Pool, EltwiseSum,
     lib, lib_path, build, reorder_oihw_to_blocked, declared_symbols,
 )

@@ -44,6 +44,16 @@ class ConcatDesc(ctypes.Structure):
                 ("channels", ctypes.POINTER(ctypes.c_int32))]
 
 
+class PoolDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("bs", "c", "ih", "iw", "oh", "ow", "kh", "kw", "sh", "sw",
+                                             "pad_t", "pad_l", "dt", "algo")]
+
+
+class EltwiseDesc(ctypes.Structure):
+    _fields_ = [("n_inputs", ctypes.c_int32), ("elems", ctypes.c_int64), ("dt", ctypes.c_int32),
+                ("post_relu", ctypes.c_int32)]
+
+
 def lib_path():
     return _LIB
 
@@ -118,6 +128,12 @@ def lib():
         "dfx_concat_submit_host": (i32, [vp, ctypes.POINTER(vp), vp]),
         "dfx_concat_submit_gathered": (i32, [vp, vp, ctypes.POINTER(ctypes.c_uint64), vp, vp]),
         "dfx_concat_destroy": (i32, [vp]),
+        "dfx_pool_create": (i32, [ctypes.POINTER(PoolDesc), ctypes.POINTER(vp)]),
+        "dfx_pool_submit": (i32, [vp, vp, vp, vp]),
+        "dfx_pool_destroy": (i32, [vp]),
+        "dfx_eltwise_create": (i32, [ctypes.POINTER(EltwiseDesc), ctypes.POINTER(vp)]),
+        "dfx_eltwise_submit": (i32, [vp, ctypes.POINTER(vp), vp, vp]),
+        "dfx_eltwise_destroy": (i32, [vp]),
         "dfx_debug_scribble_lds": (i32, [ctypes.c_uint, vp]),
         "dfx_debug_set_tuning": (i32, [ctypes.c_char_p, ctypes.c_char_p]),
     }
@@ -219,6 +235,55 @@ class Conv:
     def close(self):
         if self._h:
             lib().dfx_conv_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Pool:
+    """dfx_pool_* handle: the pooling stage of the reference's planned conv+relu+pool op (max pooling, NHWC)."""
+
+    def __init__(self, bs, c, ih, iw, oh, ow, kernel, stride, pad, np_dtype):
+        d = PoolDesc(bs, c, ih, iw, oh, ow, kernel[0], kernel[1], stride[0], stride[1], pad[0], pad[1],
+                     _DT[np.dtype(np_dtype)], 0)
+        self.dst_shape = (bs, oh, ow, c)
+        self._h = ctypes.c_void_p()
+        _check(lib().dfx_pool_create(ctypes.byref(d), ctypes.byref(self._h)))
+
+    def submit(self, src_dev, dst_dev, stream=None):
+        _check(lib().dfx_pool_submit(self._h, _dev_ptr(src_dev), _dev_ptr(dst_dev), _stream_ptr(stream)))
+
+    def close(self):
+        if self._h:
+            lib().dfx_pool_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class EltwiseSum:
+    """dfx_eltwise_* handle: the reference's planned eltwise-sum + relu op."""
+
+    def __init__(self, n_inputs, elems, np_dtype, post_relu=False):
+        d = EltwiseDesc(n_inputs, elems, _DT[np.dtype(np_dtype)], int(post_relu))
+        self._h = ctypes.c_void_p()
+        _check(lib().dfx_eltwise_create(ctypes.byref(d), ctypes.byref(self._h)))
+
+    def submit(self, srcs_dev, dst_dev, stream=None):
+        ptrs = (ctypes.c_void_p * len(srcs_dev))(*[_dev_ptr(s).value for s in srcs_dev])
+        _check(lib().dfx_eltwise_submit(self._h, ptrs, _dev_ptr(dst_dev), _stream_ptr(stream)))
+
+    def close(self):
+        if self._h:
+            lib().dfx_eltwise_destroy(self._h)
             self._h = ctypes.c_void_p()
 
     def __del__(self):

@@ -62,6 +62,8 @@ DFX_DECL(u8);
 #undef DFX_DECL
 
 int launch_concat(const ConcatArgs &a, hipStream_t s);
+int launch_pool(const PoolArgs &a, hipStream_t s);
+int launch_eltwise(const EltwiseArgs &a, hipStream_t s);
 }  // namespace dfx
 
 using namespace dfx;
@@ -1520,3 +1522,112 @@ int dfx_concat_destroy(dfx_concat_t *h) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// pooling stage of conv+relu+pool, eltwise-sum (+relu): the reference's roadmap ops
+// (README.md:64-65; semantics of the MKL-DNN pipeline in test/test_conv_relu_pooling.cc:30-235)
+// ---------------------------------------------------------------------------
+
+struct dfx_pool {
+  dfx_pool_desc d;
+  int device;
+  PoolArgs args;
+};
+struct dfx_eltwise {
+  dfx_eltwise_desc d;
+  int device;
+  EltwiseArgs args;
+};
+
+int dfx_pool_create(const dfx_pool_desc *desc, dfx_pool_t **out) {
+  if (!desc || !out) return fail(DFX_ERR_INVALID, "pool_create: null argument");
+  *out = nullptr;
+  const dfx_pool_desc &d = *desc;
+  if (d.bs <= 0 || d.c <= 0 || d.ih <= 0 || d.iw <= 0 || d.oh <= 0 || d.ow <= 0 || d.kh <= 0 || d.kw <= 0 ||
+      d.sh <= 0 || d.sw <= 0 || d.pad_t < 0 || d.pad_l < 0)
+    return fail(DFX_ERR_INVALID, "pool: bad dimension");
+  if (d.dt < DFX_F32 || d.dt > DFX_U8) return fail(DFX_ERR_INVALID, "pool: bad dtype");
+  if (d.algo != DFX_POOL_MAX) return fail(DFX_ERR_UNSUPPORTED, "pool: only max pooling is implemented");
+  // every output window must contain at least one input position (as MKL-DNN requires)
+  if (d.pad_t >= d.kh || d.pad_l >= d.kw || (long long)(d.oh - 1) * d.sh - d.pad_t >= d.ih ||
+      (long long)(d.ow - 1) * d.sw - d.pad_l >= d.iw)
+    return fail(DFX_ERR_INVALID, "pool: an output window lies entirely in the padding");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(DFX_ERR_NO_DEVICE, "pool_create: no HIP device (this library has no CPU path)");
+  dfx_pool *h = new (std::nothrow) dfx_pool();
+  if (!h) return fail(DFX_ERR_HIP, "out of host memory");
+  h->d = d;
+  if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
+  PoolArgs &a = h->args;
+  memset(&a, 0, sizeof(a));
+  a.bs = d.bs; a.c = d.c; a.ih = d.ih; a.iw = d.iw; a.oh = d.oh; a.ow = d.ow;
+  a.kh = d.kh; a.kw = d.kw; a.sh = d.sh; a.sw = d.sw; a.pad_t = d.pad_t; a.pad_l = d.pad_l; a.dt = d.dt;
+  const size_t es = dt_size(d.dt);
+  a.vec = ((size_t)d.c * es) % 16 == 0;
+  a.groups = a.vec ? (int)((size_t)d.c * es / 16) : d.c;
+  a.total = (long long)d.bs * d.oh * d.ow * a.groups;
+  *out = h;
+  return DFX_OK;
+}
+
+int dfx_pool_submit(dfx_pool_t *h, const void *src_dev, void *dst_dev, dfx_stream_t s) {
+  if (!h || !src_dev || !dst_dev) return fail(DFX_ERR_INVALID, "pool_submit: null argument");
+  DeviceGuard dg(h->device);
+  PoolArgs a = h->args;  // per-launch copy: concurrent submits on several streams are independent
+  a.src = (const unsigned char *)src_dev;
+  a.dst = (unsigned char *)dst_dev;
+  if (launch_pool(a, (hipStream_t)s) != 0) return fail(DFX_ERR_INVALID, "pool_submit: bad dtype");
+  HIP_TRY(hipGetLastError());
+  return DFX_OK;
+}
+
+int dfx_pool_destroy(dfx_pool_t *h) {
+  delete h;
+  return DFX_OK;
+}
+
+int dfx_eltwise_create(const dfx_eltwise_desc *desc, dfx_eltwise_t **out) {
+  if (!desc || !out) return fail(DFX_ERR_INVALID, "eltwise_create: null argument");
+  *out = nullptr;
+  const dfx_eltwise_desc &d = *desc;
+  if (d.n_inputs < 2 || d.n_inputs > ELTWISE_MAX_INPUTS)
+    return fail(DFX_ERR_UNSUPPORTED, "eltwise: 2..%d inputs", ELTWISE_MAX_INPUTS);
+  if (d.elems <= 0) return fail(DFX_ERR_INVALID, "eltwise: non-positive size");
+  if (d.dt < DFX_F32 || d.dt > DFX_U8) return fail(DFX_ERR_INVALID, "eltwise: bad dtype");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(DFX_ERR_NO_DEVICE, "eltwise_create: no HIP device (this library has no CPU path)");
+  dfx_eltwise *h = new (std::nothrow) dfx_eltwise();
+  if (!h) return fail(DFX_ERR_HIP, "out of host memory");
+  h->d = d;
+  if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
+  memset(&h->args, 0, sizeof(h->args));
+  h->args.n_inputs = d.n_inputs;
+  h->args.dt = d.dt;
+  h->args.relu = d.post_relu;
+  h->args.elems = d.elems;
+  *out = h;
+  return DFX_OK;
+}
+
+int dfx_eltwise_submit(dfx_eltwise_t *h, const void *const *srcs_dev, void *dst_dev, dfx_stream_t s) {
+  if (!h || !srcs_dev || !dst_dev) return fail(DFX_ERR_INVALID, "eltwise_submit: null argument");
+  DeviceGuard dg(h->device);
+  EltwiseArgs a = h->args;
+  for (int i = 0; i < a.n_inputs; ++i) {
+    if (!srcs_dev[i]) return fail(DFX_ERR_INVALID, "eltwise_submit: null input %d", i);
+    if ((uintptr_t)srcs_dev[i] % 16) return fail(DFX_ERR_INVALID, "eltwise_submit: input %d not 16-byte aligned", i);
+    a.src[i] = (const unsigned char *)srcs_dev[i];
+  }
+  if ((uintptr_t)dst_dev % 16) return fail(DFX_ERR_INVALID, "eltwise_submit: dst not 16-byte aligned");
+  a.dst = (unsigned char *)dst_dev;
+  if (launch_eltwise(a, (hipStream_t)s) != 0) return fail(DFX_ERR_INVALID, "eltwise_submit: bad dtype");
+  HIP_TRY(hipGetLastError());
+  return DFX_OK;
+}
+
+int dfx_eltwise_destroy(dfx_eltwise_t *h) {
+  delete h;
+  return DFX_OK;
+}

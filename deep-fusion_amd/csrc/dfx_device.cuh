@@ -110,4 +110,21 @@ struct ConcatArgs {
   unsigned char *dst;
 };
 
+struct PoolArgs {
+  const unsigned char *src;
+  unsigned char *dst;
+  int bs, c, ih, iw, oh, ow, kh, kw, sh, sw, pad_t, pad_l, dt;
+  int vec;              // 1: one 16-byte channel group per thread (c * element size a multiple of 16)
+  int groups;           // work items per output pixel
+  long long total;      // work items
+};
+
+constexpr int ELTWISE_MAX_INPUTS = 8;
+struct EltwiseArgs {
+  const unsigned char *src[ELTWISE_MAX_INPUTS];
+  unsigned char *dst;
+  int n_inputs, dt, relu;
+  long long elems;
+};
+
 }  // namespace dfx

@@ -1,0 +1,134 @@
+// pool_eltwise.hip -- the reference's two roadmap ops as HBM-bound element kernels (gfx950):
+//   max pooling over NHWC (the pooling stage of conv+relu+pool, README.md:64 and the MKL-DNN
+//   pipeline of test/test_conv_relu_pooling.cc:165-226) and eltwise-sum (+ReLU) (README.md:65;
+//   the "shortcut sum" post-op of test_conv_relu_pooling.cc:118-124).
+// Pooling: dst[n,oy,ox,c] = max over the window positions that lie inside the input; one thread
+// per 16 bytes of channels of one output pixel (consecutive threads = consecutive channel groups:
+// coalesced reads and writes), scalar path for channel counts that are not a 16-byte multiple.
+// Eltwise: dst[i] = relu?(saturate(sum_k src_k[i])), integers summed exactly, f32 left to right.
+#include "dfx_device.cuh"
+
+namespace dfx {
+
+template <typename T>
+__device__ __forceinline__ T pool_lowest();
+template <> __device__ __forceinline__ float pool_lowest<float>() { return -__builtin_inff(); }
+template <> __device__ __forceinline__ int pool_lowest<int>() { return (int)0x80000000; }
+template <> __device__ __forceinline__ signed char pool_lowest<signed char>() { return (signed char)-128; }
+template <> __device__ __forceinline__ unsigned char pool_lowest<unsigned char>() { return 0; }
+
+// f32 maximum with the operand order of vmaxps(acc, x): the second operand wins ties and NaNs
+__device__ __forceinline__ float pool_max(float a, float b) { return a > b ? a : b; }
+__device__ __forceinline__ int pool_max(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ signed char pool_max(signed char a, signed char b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned char pool_max(unsigned char a, unsigned char b) { return a > b ? a : b; }
+
+template <typename T, int N>  // N elements of T = 16 bytes (vec) or 1 element (scalar)
+__device__ __forceinline__ void pool_item(const PoolArgs &a, long long id) {
+  const long long px = id / a.groups;
+  const int g = (int)(id - px * a.groups);
+  const int ox = (int)(px % a.ow);
+  const long long t = px / a.ow;
+  const int oy = (int)(t % a.oh), n = (int)(t / a.oh);
+  T acc[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) acc[e] = pool_lowest<T>();
+  const int y0 = oy * a.sh - a.pad_t, x0 = ox * a.sw - a.pad_l;
+  for (int ky = 0; ky < a.kh; ++ky) {
+    const int y = y0 + ky;
+    if (y < 0 || y >= a.ih) continue;
+    for (int kx = 0; kx < a.kw; ++kx) {
+      const int x = x0 + kx;
+      if (x < 0 || x >= a.iw) continue;
+      const T *p = reinterpret_cast<const T *>(a.src) + (((size_t)n * a.ih + y) * a.iw + x) * a.c + (size_t)g * N;
+      T v[N];
+      if (N * sizeof(T) == 16) *reinterpret_cast<v4i *>(v) = *reinterpret_cast<const v4i *>(p);
+      else v[0] = p[0];
+#pragma unroll
+      for (int e = 0; e < N; ++e) acc[e] = pool_max(acc[e], v[e]);
+    }
+  }
+  T *q = reinterpret_cast<T *>(a.dst) + (size_t)px * a.c + (size_t)g * N;
+  if (N * sizeof(T) == 16) dfx_store16(reinterpret_cast<v4i *>(q), *reinterpret_cast<const v4i *>(acc));
+  else q[0] = acc[0];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < a.total; id += stride) {
+    if (a.vec) pool_item<T, 16 / (int)sizeof(T)>(a, id);
+    else pool_item<T, 1>(a, id);
+  }
+}
+
+int launch_pool(const PoolArgs &a, hipStream_t s) {
+  if (a.total == 0) return 0;
+  long long blocks = (a.total + 255) / 256;
+  if (blocks > 256 * 8) blocks = 256 * 8;  // 8 blocks per CU, grid-stride the rest
+  switch (a.dt) {
+    case DFX_F32: pool_kernel<float><<<(int)blocks, 256, 0, s>>>(a); break;
+    case DFX_S32: pool_kernel<int><<<(int)blocks, 256, 0, s>>>(a); break;
+    case DFX_S8: pool_kernel<signed char><<<(int)blocks, 256, 0, s>>>(a); break;
+    case DFX_U8: pool_kernel<unsigned char><<<(int)blocks, 256, 0, s>>>(a); break;
+    default: return -1;
+  }
+  return 0;
+}
+
+// ---- eltwise sum ----
+template <typename T> struct EltAcc { typedef long long type; };
+template <> struct EltAcc<float> { typedef float type; };
+
+__device__ __forceinline__ float elt_finish(float v, bool relu) { return relu ? relu_x86(v) : v; }
+__device__ __forceinline__ int elt_finish_i(long long v, long long lo, long long hi, bool relu) {
+  if (relu && v < 0) v = 0;
+  return (int)(v < lo ? lo : (v > hi ? hi : v));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void eltwise_kernel(EltwiseArgs a) {
+  constexpr int N = 16 / (int)sizeof(T);
+  const long long nvec = a.elems / N, stride = (long long)gridDim.x * blockDim.x;
+  const long long lo = sizeof(T) == 4 ? -2147483648LL : ((T)-1 < (T)0 ? -128 : 0);
+  const long long hi = sizeof(T) == 4 ? 2147483647LL : ((T)-1 < (T)0 ? 127 : 255);
+  for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < nvec + (a.elems - nvec * N); id += stride) {
+    const bool vec = id < nvec;
+    const long long e0 = vec ? id * N : nvec * N + (id - nvec);
+    const int cnt = vec ? N : 1;
+    typename EltAcc<T>::type acc[N];
+    for (int e = 0; e < N; ++e) acc[e] = 0;
+    for (int k = 0; k < a.n_inputs; ++k) {
+      const T *p = reinterpret_cast<const T *>(a.src[k]) + e0;
+      T v[N];
+      if (vec) *reinterpret_cast<v4i *>(v) = *reinterpret_cast<const v4i *>(p);
+      else v[0] = p[0];
+      for (int e = 0; e < cnt; ++e) acc[e] = k == 0 ? (typename EltAcc<T>::type)v[e] : acc[e] + (typename EltAcc<T>::type)v[e];
+    }
+    T out[N];
+    for (int e = 0; e < cnt; ++e) {
+      if (sizeof(typename EltAcc<T>::type) == 4) out[e] = (T)elt_finish((float)acc[e], a.relu != 0);
+      else out[e] = (T)elt_finish_i((long long)acc[e], lo, hi, a.relu != 0);
+    }
+    T *q = reinterpret_cast<T *>(a.dst) + e0;
+    if (vec) dfx_store16(reinterpret_cast<v4i *>(q), *reinterpret_cast<const v4i *>(out));
+    else q[0] = out[0];
+  }
+}
+
+int launch_eltwise(const EltwiseArgs &a, hipStream_t s) {
+  if (a.elems == 0) return 0;
+  const long long items = a.elems / (16 / (a.dt == DFX_F32 || a.dt == DFX_S32 ? 4 : 1)) + 16;
+  long long blocks = (items + 255) / 256;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+  switch (a.dt) {
+    case DFX_F32: eltwise_kernel<float><<<(int)blocks, 256, 0, s>>>(a); break;
+    case DFX_S32: eltwise_kernel<int><<<(int)blocks, 256, 0, s>>>(a); break;
+    case DFX_S8: eltwise_kernel<signed char><<<(int)blocks, 256, 0, s>>>(a); break;
+    case DFX_U8: eltwise_kernel<unsigned char><<<(int)blocks, 256, 0, s>>>(a); break;
+    default: return -1;
+  }
+  return 0;
+}
+
+}  // namespace dfx

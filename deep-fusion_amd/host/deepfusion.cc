@@ -606,7 +606,172 @@ private:
   std::vector<shard> shards_;  // DEEPFUSION_DEVICES > 1 (see op_conv)
 };
 
+// ---- conv + relu + max pooling (reference roadmap, README.md:64): the conv runs as the unfused conv
+// op into a device buffer the op owns (the intermediate never visits the host), the pooling kernel
+// reads it (from L2 / the Infinity Cache for the sizes of test_conv_relu_pooling.cc) ----
+class op_conv_pool : public op {
+public:
+  op_conv_pool(const std::unique_ptr<memory> &src, const std::unique_ptr<memory> &wei,
+               const std::unique_ptr<memory> &bia, std::array<int, 2> stride, std::array<int, 2> pad,
+               std::array<int, 2> pk, std::array<int, 2> ps, std::array<int, 2> pp, std::unique_ptr<memory> &dst,
+               bool relu, const std::vector<float> &scales, round_mode rm)
+      : src_(src.get()), wei_(wei.get()), bia_(bia.get()), dst_(dst.get()), scales_(scales), conv_(nullptr),
+        pool_(nullptr), mid_(nullptr), wei_seen_(0) {
+    using fmt = memory::format;
+    if (!src_ || !wei_ || !dst_) error_and_exit("Init ConvReluPool op failed! (null tensor)");
+    bool ok = src_->data_type() == memory::dtype::u8 && wei_->data_type() == memory::dtype::s8 &&
+              src_->dim_format() == fmt::nhwc && dst_->dim_format() == fmt::nhwc &&
+              (wei_->dim_format() == fmt::OIhw4i16o4i || wei_->dim_format() == fmt::gOIhw4i16o4i) &&
+              (!bia_ || bia_->dim_format() == fmt::x);
+    if (!ok) error_and_exit("Init ConvReluPool op failed! (data type / format)");
+    auto s = src_->std_dims(), w = wei_->std_dims(), o = dst_->std_dims();
+    if (s[0] != o[0]) error_and_exit("Init ConvReluPool op failed! (Batch size do not equal)");
+    if (s[1] != w[1]) error_and_exit("Init ConvReluPool op failed! (Input channel do not match)");
+    if (o[1] != w[0]) error_and_exit("Init ConvReluPool op failed! (Output channel do not match)");
+    if (bia_ && (int)bia_->size() != w[0]) error_and_exit("Init ConvReluPool op failed! (Bias channel do not match)");
+    // conv output size: util/math_func.cc:22-24
+    const int ch = (s[2] + 2 * pad[0] - w[2]) / stride[0] + 1, cw = (s[3] + 2 * pad[1] - w[3]) / stride[1] + 1;
+    if (ch <= 0 || cw <= 0) error_and_exit("Init ConvReluPool op failed! (conv output size)");
+    dfx_conv_desc d;
+    memset(&d, 0, sizeof(d));
+    d.bs = s[0]; d.ic = s[1]; d.ih = s[2]; d.iw = s[3];
+    d.oc = w[0]; d.kh = w[2]; d.kw = w[3]; d.oh = ch; d.ow = cw;
+    d.sh = stride[0]; d.sw = stride[1]; d.pad_t = pad[0]; d.pad_l = pad[1];
+    d.dst_dt = to_dfx_dtype(dst_->data_type());
+    d.bia0_dt = bia_ ? to_dfx_dtype(bia_->data_type()) : DFX_UNDEF;
+    d.bia1_dt = DFX_UNDEF;
+    d.conv0_relu = relu;
+    d.conv0_round_mode = rm == round_mode::down ? DFX_ROUND_DOWN : DFX_ROUND_NEAREST;
+    d.conv1_round_mode = DFX_ROUND_NEAREST;
+    d.conv0_nscales = (int)scales_.size();
+    d.conv1_nscales = 1;
+    d.force_variant = -1;
+    if (dfx_conv_create(&d, &conv_) != DFX_OK) error_and_exit("Init ConvReluPool op failed! (%s)", dfx_last_error());
+    dfx_pool_desc p;
+    memset(&p, 0, sizeof(p));
+    p.bs = s[0]; p.c = w[0]; p.ih = ch; p.iw = cw; p.oh = o[2]; p.ow = o[3];
+    p.kh = pk[0]; p.kw = pk[1]; p.sh = ps[0]; p.sw = ps[1]; p.pad_t = pp[0]; p.pad_l = pp[1];
+    p.dt = d.dst_dt;
+    p.algo = DFX_POOL_MAX;
+    if (dfx_pool_create(&p, &pool_) != DFX_OK) error_and_exit("Init ConvReluPool op failed! (%s)", dfx_last_error());
+    check_dfx(dfx_mem_alloc_device(&mid_, (size_t)s[0] * ch * cw * w[0] * dtype_size(dst_->data_type())), "device alloc");
+    st_.ensure_stream();
+  }
+  ~op_conv_pool() override {
+    dfx_conv_destroy(conv_);
+    dfx_pool_destroy(pool_);
+    dfx_mem_free_device(mid_);
+  }
+  void submit() override {
+    run(true);
+    st_.fetch_out(*dst_);
+    check_dfx(dfx_stream_sync(st_.stream), "stream sync");
+  }
+  void submit_async() override { run(false); }
+  void wait() override { check_dfx(dfx_stream_sync(st_.stream), "stream sync"); }
+
+protected:
+  void infer() override { run(true); }
+  void run(bool sync_host) {
+    unsigned long long v;
+    if (sync_host) {
+      v = detail::hash_bytes(wei_->host_data(), wei_->buffer_size(), 1469598103934665603ull);
+      if (bia_) v = detail::hash_bytes(bia_->host_data(), bia_->buffer_size(), v);
+      v |= 1ull << 63;
+    } else {
+      v = wei_->host_version() + (bia_ ? bia_->host_version() : 0);
+      if (wei_seen_ >> 63) v = wei_seen_;
+    }
+    if (v != wei_seen_) {
+      check_dfx(dfx_stream_sync(st_.stream), "stream sync");
+      check_dfx(dfx_conv_set_weights(conv_, (const int8_t *)wei_->host_data(), bia_ ? bia_->host_data() : nullptr,
+                                     scales_.data(), nullptr, nullptr, nullptr),
+                "conv set_weights");
+      wei_seen_ = v;
+    }
+    void *s = st_.sync_in(*src_, sync_host);
+    void *o = st_.device_out(*dst_);
+    st_.profile_begin();
+    check_dfx(dfx_conv_submit(conv_, s, mid_, st_.stream), "conv submit");
+    check_dfx(dfx_pool_submit(pool_, mid_, o, st_.stream), "pool submit");
+    st_.profile_end(name());
+  }
+  const char *name() override { return "conv_relu_pool"; }
+
+private:
+  memory *src_, *wei_, *bia_, *dst_;
+  std::vector<float> scales_;
+  dfx_conv_t *conv_;
+  dfx_pool_t *pool_;
+  void *mid_;
+  unsigned long long wei_seen_;
+  detail::op_state st_;
+};
+
+// ---- eltwise sum (+relu) (reference roadmap, README.md:65) ----
+class op_eltwise : public op {
+public:
+  op_eltwise(const std::vector<std::unique_ptr<memory>> &srcs, std::unique_ptr<memory> &dst, bool relu)
+      : dst_(dst.get()), h_(nullptr) {
+    if (!dst_ || srcs.size() < 2) error_and_exit("Init EltwiseSum op failed!");
+    for (auto &m : srcs) {
+      if (!m || m->dim_format() != dst_->dim_format() || m->data_type() != dst_->data_type() ||
+          m->actual_dims() != dst_->actual_dims())
+        error_and_exit("Init EltwiseSum op failed! (format / data type / shape)");
+      srcs_.push_back(m.get());
+    }
+    dfx_eltwise_desc d;
+    d.n_inputs = (int)srcs_.size();
+    d.elems = (long long)dst_->size();
+    d.dt = to_dfx_dtype(dst_->data_type());
+    d.post_relu = relu;
+    if (dfx_eltwise_create(&d, &h_) != DFX_OK) error_and_exit("Init EltwiseSum op failed! (%s)", dfx_last_error());
+    st_.ensure_stream();
+  }
+  ~op_eltwise() override { dfx_eltwise_destroy(h_); }
+  void submit() override {
+    run(true);
+    st_.fetch_out(*dst_);
+    check_dfx(dfx_stream_sync(st_.stream), "stream sync");
+  }
+  void submit_async() override { run(false); }
+  void wait() override { check_dfx(dfx_stream_sync(st_.stream), "stream sync"); }
+
+protected:
+  void infer() override { run(true); }
+  void run(bool sync_host) {
+    std::vector<const void *> p;
+    for (memory *m : srcs_) p.push_back(st_.sync_in(*m, sync_host));
+    void *o = st_.device_out(*dst_);
+    st_.profile_begin();
+    check_dfx(dfx_eltwise_submit(h_, p.data(), o, st_.stream), "eltwise submit");
+    st_.profile_end(name());
+  }
+  const char *name() override { return "eltwise_sum"; }
+
+private:
+  std::vector<memory *> srcs_;
+  memory *dst_;
+  dfx_eltwise_t *h_;
+  detail::op_state st_;
+};
+
 }  // namespace
+
+std::unique_ptr<op> conv_relu_pool(const std::unique_ptr<memory> &src, const std::unique_ptr<memory> &wei,
+                                   const std::unique_ptr<memory> &bia, std::array<int, 2> conv_stride,
+                                   std::array<int, 2> conv_padding, std::array<int, 2> pool_kernel,
+                                   std::array<int, 2> pool_stride, std::array<int, 2> pool_padding,
+                                   std::unique_ptr<memory> &dst, bool conv_relu, std::vector<float> conv_scales,
+                                   round_mode conv_round_mode) {
+  return std::unique_ptr<op>(new op_conv_pool(src, wei, bia, conv_stride, conv_padding, pool_kernel, pool_stride,
+                                              pool_padding, dst, conv_relu, conv_scales, conv_round_mode));
+}
+
+std::unique_ptr<op> eltwise_sum(const std::vector<std::unique_ptr<memory>> &srcs, std::unique_ptr<memory> &dst,
+                                bool post_relu) {
+  return std::unique_ptr<op>(new op_eltwise(srcs, dst, post_relu));
+}
 
 // ---------------------------------------------------------------------------
 // factories (reference deepfusion.cc:105-185)

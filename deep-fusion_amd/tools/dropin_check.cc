@@ -134,6 +134,42 @@ int main(int argc, char **argv) {
     c->submit();
     dump(out + "/concat_s8_dst.bin", dst->data(), dst->buffer_size());
   }
+  // ---- conv + relu + 2x2/2 max pool (roadmap op; first VGG-style shape of test_conv_relu_pooling.cc:322-324
+  //      scaled to 32 channels, odd image size so the pool windows hang over the edge) ----
+  {
+    const int bs = 3, ic = 32, ih = 11, iw = 9, oc = 48, ph = 6, pw = 5;
+    std::unique_ptr<memory> src(new memory(memory::nchw_dims{bs, ic, ih, iw}, memory::format::nhwc, memory::dtype::u8));
+    std::unique_ptr<memory> wei(new memory(memory::nchw_dims{oc, ic, 3, 3}, memory::format::OIhw4i16o4i, memory::dtype::s8));
+    std::unique_ptr<memory> bia(new memory(memory::dims{oc}, memory::format::x, memory::dtype::s32));
+    std::unique_ptr<memory> dst(new memory(memory::nchw_dims{bs, oc, ph, pw}, memory::format::nhwc, memory::dtype::u8));
+    uint8_t *s = (uint8_t *)src->data();
+    for (size_t i = 0; i < src->size(); ++i) s[i] = (uint8_t)(g.next() % 64);
+    std::vector<s8> w0(wei->size());
+    for (auto &v : w0) v = (s8)((int)(g.next() % 21) - 10);
+    reorder_weights(w0.data(), wei);
+    int32_t *b0 = (int32_t *)bia->data();
+    for (int i = 0; i < oc; ++i) b0[i] = (int)(g.next() % 201) - 100;
+    auto c = conv_relu_pool(src, wei, bia, {1, 1}, {1, 1}, {2, 2}, {2, 2}, {0, 0}, dst, true, {1.f / 32});
+    c->submit();
+    dump(out + "/pool_src.bin", src->host_data(), src->buffer_size());
+    dump(out + "/pool_w0_oihw.bin", w0.data(), w0.size());
+    dump(out + "/pool_b0.bin", bia->host_data(), bia->buffer_size());
+    dump(out + "/pool_dst.bin", dst->data(), dst->buffer_size());
+  }
+  // ---- eltwise sum + relu of three s8 tensors (roadmap op) ----
+  {
+    std::vector<std::unique_ptr<memory>> srcs;
+    for (int k = 0; k < 3; ++k) {
+      srcs.emplace_back(new memory(memory::nchw_dims{2, 24, 5, 7}, memory::format::nhwc, memory::dtype::s8));
+      s8 *p = (s8 *)srcs.back()->data();
+      for (size_t i = 0; i < srcs.back()->size(); ++i) p[i] = (s8)((int)(g.next() % 256) - 128);
+      dump(out + "/elt_s8_src" + std::to_string(k) + ".bin", p, srcs.back()->buffer_size());
+    }
+    std::unique_ptr<memory> dst(new memory(memory::nchw_dims{2, 24, 5, 7}, memory::format::nhwc, memory::dtype::s8));
+    auto c = eltwise_sum(srcs, dst, true);
+    c->submit();
+    dump(out + "/elt_s8_dst.bin", dst->data(), dst->buffer_size());
+  }
   printf("dropin_check wrote results to %s\n", out.c_str());
   return 0;
 }

@@ -174,6 +174,30 @@ std::unique_ptr<op> conv(const std::unique_ptr<memory> &src,
                          std::vector<float> conv1_scales = {1.f},
                          round_mode conv1_round_mode = round_mode::nearest);
 
+// ---- the reference's roadmap ops (README.md:64-65), which it never shipped.  Signature after the
+// planned one in test/test_conv_relu_pooling.cc:264-281; semantics of the MKL-DNN pipeline that test
+// builds (:30-235): conv (+bias, scale, round) -> relu -> max pooling whose padding takes no part.
+// `dst` carries the pooled dims; the conv output dims follow from src / wei / stride / padding. ----
+std::unique_ptr<op> conv_relu_pool(const std::unique_ptr<memory> &src,
+                                   const std::unique_ptr<memory> &wei,
+                                   const std::unique_ptr<memory> &bia,
+                                   std::array<int, 2> conv_stride,
+                                   std::array<int, 2> conv_padding,
+                                   std::array<int, 2> pool_kernel,
+                                   std::array<int, 2> pool_stride,
+                                   std::array<int, 2> pool_padding,
+                                   std::unique_ptr<memory> &dst,
+                                   bool conv_relu = true,
+                                   std::vector<float> conv_scales = {1.f},
+                                   round_mode conv_round_mode = round_mode::nearest);
+
+// dst = relu?(saturate(sum of srcs)): same shape, format and dtype everywhere; integer sums are
+// exact and saturate to the dtype's range, f32 sums run left to right (README.md:65, the "shortcut
+// sum" of test_conv_relu_pooling.cc:118-124)
+std::unique_ptr<op> eltwise_sum(const std::vector<std::unique_ptr<memory>> &srcs,
+                                std::unique_ptr<memory> &dst,
+                                bool post_relu = true);
+
 // ---- extension: the reorder the reference never shipped (deepfusion.cc:44-50) ----
 // Writes plain oihw s8 weights into `blocked` (an OIhw4i16o4i memory of the same
 // logical dims) in the [O/16][I/16][kh][kw][4i][16o][4i] byte order.

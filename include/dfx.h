@@ -97,6 +97,31 @@ typedef struct dfx_concat_desc {
 
 typedef struct dfx_conv dfx_conv_t;
 typedef struct dfx_concat dfx_concat_t;
+
+/* ---- the reference's roadmap ops (README.md:64-65: "conv+relu+pooling fused op",
+ *      "eltwise-sum + relu fused op"; planned signature in test/test_conv_relu_pooling.cc:264-281).
+ *      The reference ships no implementation: semantics follow the MKL-DNN pipeline its test
+ *      builds (test_conv_relu_pooling.cc:30-235).  Parity unpinned. ---- */
+typedef enum dfx_pool_algo { DFX_POOL_MAX = 0 } dfx_pool_algo;
+typedef struct dfx_pool_desc {
+  int32_t bs, c, ih, iw;    /* NHWC input (the conv's output) */
+  int32_t oh, ow;           /* given by the caller like the reference's dst_dims; windows may hang over the
+                               bottom / right edge (the test's padR search, test_conv_relu_pooling.cc:178-182) */
+  int32_t kh, kw, sh, sw, pad_t, pad_l;
+  int32_t dt;               /* dfx_dtype of src and dst */
+  int32_t algo;             /* DFX_POOL_MAX: maximum over the window's positions INSIDE the input
+                               (padding does not take part, as in MKL-DNN's pooling_max) */
+} dfx_pool_desc;
+typedef struct dfx_pool dfx_pool_t;
+
+typedef struct dfx_eltwise_desc {
+  int32_t n_inputs;         /* 2..8 tensors of identical shape and dtype */
+  int64_t elems;            /* elements per tensor */
+  int32_t dt;
+  int32_t post_relu;        /* dst = relu?(saturate(sum_i src_i)): integer sums are exact and saturate to the
+                               dtype's range, f32 sums left to right */
+} dfx_eltwise_desc;
+typedef struct dfx_eltwise dfx_eltwise_t;
 typedef void *dfx_stream_t; /* a hipStream_t; NULL = the default stream */
 typedef void *dfx_event_t;  /* a hipEvent_t */
 
@@ -174,6 +199,14 @@ int dfx_concat_submit_host(dfx_concat_t *h, const void *const *srcs_host, void *
 int dfx_concat_submit_gathered(dfx_concat_t *h, const void *gathered_dev,
                                const uint64_t *offsets, void *dst_dev, dfx_stream_t s);
 int dfx_concat_destroy(dfx_concat_t *h);
+
+/* ---- pooling stage of conv+relu+pool, eltwise-sum(+relu) (see the descriptors above) ---- */
+int dfx_pool_create(const dfx_pool_desc *desc, dfx_pool_t **out);
+int dfx_pool_submit(dfx_pool_t *h, const void *src_dev, void *dst_dev, dfx_stream_t s);
+int dfx_pool_destroy(dfx_pool_t *h);
+int dfx_eltwise_create(const dfx_eltwise_desc *desc, dfx_eltwise_t **out);
+int dfx_eltwise_submit(dfx_eltwise_t *h, const void *const *srcs_dev, void *dst_dev, dfx_stream_t s);
+int dfx_eltwise_destroy(dfx_eltwise_t *h);
 
 /* ---- test hooks (not part of the reference's surface; used by tests/ only) ---- */
 /* Overwrites the LDS of every CU with a pattern (asynchronous, on `s`): makes a kernel that

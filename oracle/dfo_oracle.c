@@ -260,3 +260,69 @@ int dfo_concat(int n_inputs, const void *const *srcs, const int *channels, int b
   }
   return 0;
 }
+
+/* ---- the reference's roadmap ops (README.md:64-65), semantics of the MKL-DNN pipeline in
+ * test/test_conv_relu_pooling.cc:165-226 (pooling_max over NHWC, padding takes no part) and
+ * :118-124 (sum post-op).  The reference has no implementation: parity unpinned. ---- */
+int dfo_maxpool(const void *src, void *dst, int bs, int c, int ih, int iw, int oh, int ow, int kh, int kw,
+                int sh, int sw, int pad_t, int pad_l, int dt) {
+  if (!src || !dst || dt < DFO_F32 || dt > DFO_U8) return -1;
+  for (int n = 0; n < bs; ++n)
+    for (int oy = 0; oy < oh; ++oy)
+      for (int ox = 0; ox < ow; ++ox)
+        for (int ch = 0; ch < c; ++ch) {
+          int first = 1;
+          float bf = 0.f;
+          long long bi = 0;
+          for (int ky = 0; ky < kh; ++ky) {
+            const int y = oy * sh - pad_t + ky;
+            if (y < 0 || y >= ih) continue;
+            for (int kx = 0; kx < kw; ++kx) {
+              const int x = ox * sw - pad_l + kx;
+              if (x < 0 || x >= iw) continue;
+              const size_t i = (((size_t)n * ih + y) * iw + x) * c + ch;
+              if (dt == DFO_F32) {
+                const float v = ((const float *)src)[i];
+                bf = first ? (-INFINITY > v ? -INFINITY : v) : (bf > v ? bf : v); /* vmaxps(acc, v) order */
+              } else {
+                const long long v = dt == DFO_S32 ? ((const int32_t *)src)[i]
+                                  : dt == DFO_S8 ? ((const int8_t *)src)[i] : ((const uint8_t *)src)[i];
+                bi = first ? v : (bi > v ? bi : v);
+              }
+              first = 0;
+            }
+          }
+          if (first) return -2; /* a window entirely in the padding */
+          const size_t o = (((size_t)n * oh + oy) * ow + ox) * c + ch;
+          if (dt == DFO_F32) ((float *)dst)[o] = bf;
+          else if (dt == DFO_S32) ((int32_t *)dst)[o] = (int32_t)bi;
+          else if (dt == DFO_S8) ((int8_t *)dst)[o] = (int8_t)bi;
+          else ((uint8_t *)dst)[o] = (uint8_t)bi;
+        }
+  return 0;
+}
+
+int dfo_eltwise_sum(int n_inputs, const void *const *srcs, void *dst, long long elems, int dt, int post_relu) {
+  if (!srcs || !dst || n_inputs < 1 || dt < DFO_F32 || dt > DFO_U8) return -1;
+  for (long long i = 0; i < elems; ++i) {
+    if (dt == DFO_F32) {
+      float a = ((const float *)srcs[0])[i];
+      for (int k = 1; k < n_inputs; ++k) a = a + ((const float *)srcs[k])[i];
+      if (post_relu) a = (0.0f > a) ? 0.0f : a; /* vmaxps(zero, a) */
+      ((float *)dst)[i] = a;
+    } else {
+      long long a = 0;
+      for (int k = 0; k < n_inputs; ++k)
+        a += dt == DFO_S32 ? ((const int32_t *)srcs[k])[i] : dt == DFO_S8 ? ((const int8_t *)srcs[k])[i]
+                                                                         : ((const uint8_t *)srcs[k])[i];
+      if (post_relu && a < 0) a = 0;
+      const long long lo = dt == DFO_S32 ? INT32_MIN : dt == DFO_S8 ? -128 : 0;
+      const long long hi = dt == DFO_S32 ? INT32_MAX : dt == DFO_S8 ? 127 : 255;
+      a = a < lo ? lo : (a > hi ? hi : a);
+      if (dt == DFO_S32) ((int32_t *)dst)[i] = (int32_t)a;
+      else if (dt == DFO_S8) ((int8_t *)dst)[i] = (int8_t)a;
+      else ((uint8_t *)dst)[i] = (uint8_t)a;
+    }
+  }
+  return 0;
+}

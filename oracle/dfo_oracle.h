@@ -102,6 +102,15 @@ int dfo_conv_scalar_mt(const dfo_conv_desc *d, const uint8_t *src,
 int dfo_concat(int n_inputs, const void *const *srcs, const int *channels,
                int bs, int h, int w, int dt, int post_relu, void *dst);
 
+/* The reference's roadmap ops (README.md:64-65); semantics of the MKL-DNN pipeline its test builds
+ * (test/test_conv_relu_pooling.cc:165-226 pooling_max: padding takes no part; :118-124 sum post-op).
+ * No reference implementation exists: parity unpinned.  dfo_maxpool returns -2 when an output window
+ * lies entirely in the padding. */
+int dfo_maxpool(const void *src, void *dst, int bs, int c, int ih, int iw, int oh, int ow, int kh, int kw,
+                int sh, int sw, int pad_t, int pad_l, int dt);
+/* dst = relu?(saturate(sum_k src_k)): integers exact + saturated to the dtype, f32 left to right */
+int dfo_eltwise_sum(int n_inputs, const void *const *srcs, void *dst, long long elems, int dt, int post_relu);
+
 /* conv_output_size, util/math_func.cc:22-24 */
 int dfo_conv_out_size(int image, int kernel, int stride, int padding);
 

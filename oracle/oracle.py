@@ -32,8 +32,9 @@ class ConvDesc(ctypes.Structure):
 
 def build(force=False):
     """Compile oracle/libdfx_oracle.so with the committed Makefile."""
-    if force or not os.path.exists(_LIB_PATH):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    # always through make (a no-op when the library is newer than its sources): a stale library
+    # after a source change must not pass for the oracle
+    subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB_PATH
 
 
@@ -54,6 +55,10 @@ def lib():
         L.dfo_concat.argtypes = [ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int),
                                  ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                  ctypes.c_int, vp]
+        L.dfo_maxpool.restype = ctypes.c_int
+        L.dfo_maxpool.argtypes = [vp, vp] + [ctypes.c_int] * 13
+        L.dfo_eltwise_sum.restype = ctypes.c_int
+        L.dfo_eltwise_sum.argtypes = [ctypes.c_int, ctypes.POINTER(vp), vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int]
         L.dfo_reorder_oihw_to_blocked.restype = None
         L.dfo_reorder_oihw_to_blocked.argtypes = [vp, vp] + [ctypes.c_int] * 4
         L.dfo_have_avx512_vnni.restype = ctypes.c_int
@@ -139,6 +144,30 @@ def concat(srcs, post_relu=False):
     rc = lib().dfo_concat(len(srcs), ptrs, ch, bs, h, w, dt, int(post_relu), _ptr(dst))
     if rc != 0:
         raise RuntimeError("oracle concat failed with code %d" % rc)
+    return dst
+
+
+def maxpool(src, kernel, stride, pad, out_hw):
+    """src: NHWC ndarray; max pooling over the window positions inside the input -> (bs, oh, ow, c)."""
+    src = np.ascontiguousarray(src)
+    bs, ih, iw, c = src.shape
+    oh, ow = out_hw
+    dst = np.zeros((bs, oh, ow, c), dtype=src.dtype)
+    rc = lib().dfo_maxpool(_ptr(src), _ptr(dst), bs, c, ih, iw, oh, ow, kernel[0], kernel[1], stride[0], stride[1],
+                           pad[0], pad[1], DT_OF[src.dtype])
+    if rc != 0:
+        raise RuntimeError("oracle maxpool failed with code %d" % rc)
+    return dst
+
+
+def eltwise_sum(srcs, post_relu=False):
+    """srcs: list of equally shaped ndarrays of one dtype -> relu?(saturate(sum))."""
+    srcs = [np.ascontiguousarray(s) for s in srcs]
+    ptrs = (ctypes.c_void_p * len(srcs))(*[s.ctypes.data for s in srcs])
+    dst = np.zeros_like(srcs[0])
+    rc = lib().dfo_eltwise_sum(len(srcs), ptrs, _ptr(dst), srcs[0].size, DT_OF[srcs[0].dtype], int(post_relu))
+    if rc != 0:
+        raise RuntimeError("oracle eltwise_sum failed with code %d" % rc)
     return dst
 
 

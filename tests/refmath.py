@@ -62,3 +62,37 @@ def conv_ref(case, data):
     relu1 = case.relu1 or case.dst_dt == U8
     f1 = _requant(acc1, data["bia1"], data["scales1"], relu1)
     return _store(f1, case.dst_dt, case.rm1)
+
+
+def maxpool(src, kernel, stride, pad, out_hw):
+    """Independent formulation of NHWC max pooling (padding takes no part): pad with the dtype's lowest
+    value, then maximum over shifted strided views -- no loop over output positions."""
+    bs, ih, iw, c = src.shape
+    oh, ow = out_hw
+    low = -np.inf if src.dtype == np.float32 else np.iinfo(src.dtype).min
+    need_h = (oh - 1) * stride[0] + kernel[0]
+    need_w = (ow - 1) * stride[1] + kernel[1]
+    buf = np.full((bs, max(need_h, pad[0] + ih), max(need_w, pad[1] + iw), c), low, dtype=src.dtype)
+    buf[:, pad[0]:pad[0] + ih, pad[1]:pad[1] + iw, :] = src
+    out = None
+    for ky in range(kernel[0]):
+        for kx in range(kernel[1]):
+            v = buf[:, ky:ky + (oh - 1) * stride[0] + 1:stride[0], kx:kx + (ow - 1) * stride[1] + 1:stride[1], :]
+            out = v.copy() if out is None else np.maximum(out, v)
+    return out
+
+
+def eltwise_sum(srcs, post_relu=False):
+    """Independent formulation: exact integer sum in int64 (f32: left to right in f32), clip, relu."""
+    if srcs[0].dtype == np.float32:
+        acc = srcs[0].copy()
+        for s in srcs[1:]:
+            acc = (acc + s).astype(np.float32)
+        return np.where(acc < 0, np.float32(0), acc).astype(np.float32) if post_relu else acc
+    acc = np.zeros(srcs[0].shape, dtype=np.int64)
+    for s in srcs:
+        acc += s.astype(np.int64)
+    if post_relu:
+        acc = np.maximum(acc, 0)
+    info = np.iinfo(srcs[0].dtype)
+    return np.clip(acc, info.min, info.max).astype(srcs[0].dtype)

@@ -67,6 +67,17 @@ def test_dropin_cpp_api(oracle, tmp_path):
     srcs = [_load(d, "concat_s8_src%d.bin" % k, np.int8, (2, 3, 3, c)) for k, c in enumerate((16, 32, 64))]
     ref = oracle.concat(srcs, True)
     assert np.array_equal(_load(d, "concat_s8_dst.bin", np.int8, ref.shape), ref)
+    # roadmap ops: conv + relu + 2x2/2 max pool (windows hang over the bottom / right edge), eltwise sum + relu
+    src = _load(d, "pool_src.bin", np.uint8, (3, 11, 9, 32))
+    w0 = _load(d, "pool_w0_oihw.bin", np.int8, (48, 32, 3, 3))
+    b0 = _load(d, "pool_b0.bin", np.int32)
+    mid = oracle.conv(src, oracle.reorder_oihw_to_blocked(w0), w0.shape, (1, 1), (1, 1), C.U8,
+                      np.array([1.0 / 32], dtype=np.float32), bia0=b0, relu0=True)
+    ref = oracle.maxpool(mid, (2, 2), (2, 2), (0, 0), (6, 5))
+    assert np.array_equal(_load(d, "pool_dst.bin", np.uint8, ref.shape), ref)
+    srcs = [_load(d, "elt_s8_src%d.bin" % k, np.int8, (2, 5, 7, 24)) for k in range(3)]
+    ref = oracle.eltwise_sum(srcs, True)
+    assert np.array_equal(_load(d, "elt_s8_dst.bin", np.int8, ref.shape), ref)
 
 
 def test_bench_tools_run():

@@ -432,6 +432,37 @@ def test_concat(hip, oracle):
                     op.close()
 
 
+def test_maxpool_and_eltwise_sum(hip, oracle):
+    """the reference's roadmap ops through the C ABI (dfx_pool_*, dfx_eltwise_*), bit-exact against the
+    oracle (parity unpinned: the reference ships no implementation, test/test_conv_relu_pooling.cc:231-281)."""
+    import torch
+    from test_oracle import POOL_CASES, pool_input
+    for np_dt in (np.uint8, np.int8, np.int32, np.float32):
+        for shape, k, s, p, o in POOL_CASES:
+            x = pool_input(shape, np_dt, seed=3)
+            op = hip.dfa.Pool(shape[0], shape[3], shape[1], shape[2], o[0], o[1], k, s, p, np_dt)
+            src = torch.from_numpy(x).cuda()
+            dst = torch.empty(op.dst_shape, dtype=src.dtype, device="cuda")
+            dst.view(torch.uint8).fill_(0xCD)
+            op.submit(src, dst)
+            torch.cuda.synchronize()
+            hip.assert_bit_equal(dst.cpu().numpy(), oracle.maxpool(x, k, s, p, o), "maxpool %s %s" % (shape, np_dt))
+            op.close()
+        for shape, n in (((2, 5, 7, 24), 3), ((1, 1, 1, 1), 2), ((3, 9, 4, 17), 8), ((4, 56, 56, 64), 2)):
+            xs = [pool_input(shape, np_dt, seed=20 + i) for i in range(n)]
+            for relu in (False, True):
+                op = hip.dfa.EltwiseSum(n, xs[0].size, np_dt, relu)
+                dsrcs = [torch.from_numpy(v).cuda() for v in xs]
+                dst = torch.empty(shape, dtype=dsrcs[0].dtype, device="cuda")
+                dst.view(torch.uint8).fill_(0xCD)
+                op.submit(dsrcs, dst)
+                torch.cuda.synchronize()
+                hip.assert_bit_equal(dst.cpu().numpy(), oracle.eltwise_sum(xs, relu), "eltwise %s %s" % (shape, np_dt))
+                op.close()
+    with pytest.raises(hip.dfa.DfxError):  # an output window entirely in the padding
+        hip.dfa.Pool(1, 16, 4, 4, 4, 4, (2, 2), (2, 2), (0, 0), np.uint8)
+
+
 def test_concat_golden(hip):
     import torch
     for np_dt in (np.float32, np.int32, np.int8, np.uint8):

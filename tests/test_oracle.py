@@ -150,3 +150,58 @@ def test_golden_vectors(oracle):
             if impl == "avx512" and not oracle.have_avx512_vnni():
                 continue
             assert_same(run_oracle(oracle, case, data, impl), z["dst"])
+
+
+# ---- the reference's roadmap ops (README.md:64-65); shapes after test/test_conv_relu_pooling.cc:313-338
+# (2x2 stride-2 max pooling behind VGG-style convs, 7x7 global window), plus windows that hang over the
+# edges, padding, odd channel counts.  No reference implementation or vectors exist: parity unpinned --
+# the oracle is checked against an independent numpy formulation only. ----
+POOL_CASES = [
+    # (n, h, w, c), kernel, stride, pad, (oh, ow)
+    ((1, 2, 2, 16), (2, 2), (2, 2), (0, 0), (1, 1)),
+    ((1, 224, 224, 16), (2, 2), (2, 2), (0, 0), (112, 112)),
+    ((2, 56, 56, 64), (2, 2), (2, 2), (0, 0), (28, 28)),
+    ((3, 7, 7, 48), (7, 7), (7, 7), (0, 0), (1, 1)),
+    ((2, 11, 9, 32), (2, 2), (2, 2), (0, 0), (6, 5)),      # windows over the bottom / right edge
+    ((2, 13, 12, 20), (3, 3), (2, 2), (1, 1), (7, 6)),     # ResNet-stem style 3x3/2 pad 1
+    ((1, 5, 6, 3), (3, 2), (1, 2), (1, 0), (5, 3)),        # odd channel count: scalar path
+    ((4, 9, 9, 5), (3, 3), (3, 3), (0, 0), (3, 3)),
+]
+
+
+def pool_input(shape, np_dt, seed=0):
+    rng = np.random.default_rng(seed)
+    if np_dt == np.float32:
+        return (rng.standard_normal(shape) * 100).astype(np.float32)
+    info = np.iinfo(np_dt)
+    return rng.integers(info.min, int(info.max) + 1, shape).astype(np_dt)
+
+
+@pytest.mark.parametrize("np_dt", [np.uint8, np.int8, np.int32, np.float32])
+@pytest.mark.parametrize("case", POOL_CASES, ids=lambda c: "x".join(map(str, c[0])))
+def test_maxpool_oracle_vs_independent(oracle, case, np_dt):
+    shape, k, s, p, o = case
+    if shape[1] > 100 and np_dt != np.uint8:
+        pytest.skip("large shape once")
+    x = pool_input(shape, np_dt)
+    assert np.array_equal(oracle.maxpool(x, k, s, p, o), refmath.maxpool(x, k, s, p, o))
+
+
+def test_maxpool_oracle_rejects_window_in_padding(oracle):
+    with pytest.raises(RuntimeError):
+        oracle.maxpool(np.zeros((1, 4, 4, 16), np.uint8), (2, 2), (2, 2), (0, 0), (4, 4))
+
+
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("np_dt", [np.uint8, np.int8, np.int32, np.float32])
+def test_eltwise_sum_oracle_vs_independent(oracle, np_dt, relu):
+    for shape, n in (((2, 5, 7, 24), 3), ((1, 1, 1, 1), 2), ((3, 9, 4, 17), 8)):
+        xs = [pool_input(shape, np_dt, seed=10 + k) for k in range(n)]
+        a, b = oracle.eltwise_sum(xs, relu), refmath.eltwise_sum(xs, relu)
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    if np_dt != np.float32:  # saturation at both ends
+        info = np.iinfo(np_dt)
+        xs = [np.full((4, 4), info.max, np_dt), np.full((4, 4), info.max, np_dt)]
+        assert (oracle.eltwise_sum(xs, relu) == info.max).all()
+        xs = [np.full((4, 4), info.min, np_dt), np.full((4, 4), info.min, np_dt)]
+        assert (oracle.eltwise_sum(xs, relu) == (0 if relu else info.min)).all()
