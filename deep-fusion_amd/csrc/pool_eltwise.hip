@@ -77,42 +77,53 @@ int launch_pool(const PoolArgs &a, hipStream_t s) {
 }
 
 // ---- eltwise sum ----
-template <typename T> struct EltAcc { typedef long long type; };
+template <typename T> struct EltAcc { typedef int type; };                 // 1-byte types: <= 8 x 255 fits an int
+template <> struct EltAcc<int> { typedef long long type; };
 template <> struct EltAcc<float> { typedef float type; };
 
-__device__ __forceinline__ float elt_finish(float v, bool relu) { return relu ? relu_x86(v) : v; }
-__device__ __forceinline__ int elt_finish_i(long long v, long long lo, long long hi, bool relu) {
+template <typename T>
+__device__ __forceinline__ T elt_finish(typename EltAcc<T>::type v, bool relu);
+template <> __device__ __forceinline__ float elt_finish<float>(float v, bool relu) { return relu ? relu_x86(v) : v; }
+template <> __device__ __forceinline__ int elt_finish<int>(long long v, bool relu) {
   if (relu && v < 0) v = 0;
-  return (int)(v < lo ? lo : (v > hi ? hi : v));
+  return (int)(v < -2147483648LL ? -2147483648LL : (v > 2147483647LL ? 2147483647LL : v));
+}
+template <> __device__ __forceinline__ signed char elt_finish<signed char>(int v, bool relu) {
+  return (signed char)min(127, max(relu ? 0 : -128, v));
+}
+template <> __device__ __forceinline__ unsigned char elt_finish<unsigned char>(int v, bool) {
+  return (unsigned char)min(255, v);  // (sums of u8 are never negative: relu is the identity)
+}
+
+template <typename T, int N>  // N elements starting at e0: 16 bytes (N = 16 / sizeof(T)) or one element
+__device__ __forceinline__ void eltwise_item(const EltwiseArgs &a, long long e0) {
+  typename EltAcc<T>::type acc[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) acc[e] = 0;
+  for (int k = 0; k < a.n_inputs; ++k) {
+    const T *p = reinterpret_cast<const T *>(a.src[k]) + e0;
+    T v[N];
+    if (N * sizeof(T) == 16) *reinterpret_cast<v4i *>(v) = *reinterpret_cast<const v4i *>(p);
+    else v[0] = p[0];
+#pragma unroll
+    for (int e = 0; e < N; ++e)  // (f32: the first term is taken as it is, then left to right)
+      acc[e] = k == 0 ? (typename EltAcc<T>::type)v[e] : acc[e] + (typename EltAcc<T>::type)v[e];
+  }
+  T out[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) out[e] = elt_finish<T>(acc[e], a.relu != 0);
+  T *q = reinterpret_cast<T *>(a.dst) + e0;
+  if (N * sizeof(T) == 16) dfx_store16(reinterpret_cast<v4i *>(q), *reinterpret_cast<const v4i *>(out));
+  else q[0] = out[0];
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void eltwise_kernel(EltwiseArgs a) {
   constexpr int N = 16 / (int)sizeof(T);
-  const long long nvec = a.elems / N, stride = (long long)gridDim.x * blockDim.x;
-  const long long lo = sizeof(T) == 4 ? -2147483648LL : ((T)-1 < (T)0 ? -128 : 0);
-  const long long hi = sizeof(T) == 4 ? 2147483647LL : ((T)-1 < (T)0 ? 127 : 255);
-  for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < nvec + (a.elems - nvec * N); id += stride) {
-    const bool vec = id < nvec;
-    const long long e0 = vec ? id * N : nvec * N + (id - nvec);
-    const int cnt = vec ? N : 1;
-    typename EltAcc<T>::type acc[N];
-    for (int e = 0; e < N; ++e) acc[e] = 0;
-    for (int k = 0; k < a.n_inputs; ++k) {
-      const T *p = reinterpret_cast<const T *>(a.src[k]) + e0;
-      T v[N];
-      if (vec) *reinterpret_cast<v4i *>(v) = *reinterpret_cast<const v4i *>(p);
-      else v[0] = p[0];
-      for (int e = 0; e < cnt; ++e) acc[e] = k == 0 ? (typename EltAcc<T>::type)v[e] : acc[e] + (typename EltAcc<T>::type)v[e];
-    }
-    T out[N];
-    for (int e = 0; e < cnt; ++e) {
-      if (sizeof(typename EltAcc<T>::type) == 4) out[e] = (T)elt_finish((float)acc[e], a.relu != 0);
-      else out[e] = (T)elt_finish_i((long long)acc[e], lo, hi, a.relu != 0);
-    }
-    T *q = reinterpret_cast<T *>(a.dst) + e0;
-    if (vec) dfx_store16(reinterpret_cast<v4i *>(q), *reinterpret_cast<const v4i *>(out));
-    else q[0] = out[0];
+  const long long nvec = a.elems / N, tail = a.elems - nvec * N, stride = (long long)gridDim.x * blockDim.x;
+  for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < nvec + tail; id += stride) {
+    if (id < nvec) eltwise_item<T, N>(a, id * N);
+    else eltwise_item<T, 1>(a, nvec * N + (id - nvec));
   }
 }
 
