@@ -150,6 +150,9 @@ struct dfx_conv {
   // launches (3x3 -> u8 intermediate in global memory -> 1x1), each with (unit, chunk) items
   dfx_conv *split0, *split1;
   void *d_mid;
+  hipEvent_t split_done;   // split ops: recorded behind the second launch; the next submit's first launch waits
+  hipStream_t split_last;  // for it when it runs on another stream (the two launches share d_mid)
+  std::mutex *split_mu;    // split ops: orders concurrent submits from several host threads
   int icb, ocb, G, grid, block, lds;
   void *d_wei, *d_wei1, *d_consts;
   int *d_queue;  // MFMA variant: ring of DFX_QUEUE_RING x {next unit, finished loaders}, one slot per launch in flight
@@ -610,6 +613,8 @@ static void conv_release(dfx_conv *h) {
   (void)hipFree(h->d_src); (void)hipFree(h->d_dst); (void)hipFree(h->d_queue);
   (void)hipFree(h->d_prof);
   (void)hipFree(h->d_mid);
+  if (h->split_done) (void)hipEventDestroy(h->split_done);
+  delete h->split_mu;
   conv_release(h->split0);
   conv_release(h->split1);
   delete h;
@@ -784,6 +789,12 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
         conv_release(h->split0); conv_release(h->split1);
         (void)hipFree(h->d_mid);
         h->split0 = h->split1 = nullptr; h->d_mid = nullptr;  // fall back to the single fused launch
+      } else {
+        h->split_mu = new (std::nothrow) std::mutex();
+        if (!h->split_mu || hipEventCreateWithFlags(&h->split_done, hipEventDisableTiming) != hipSuccess) {
+          conv_release(h);
+          return fail(DFX_ERR_HIP, "conv_create: cannot create the split op's ordering event");
+        }
       }
     }
     if (const char *e = tune("DFX_STREAM_GRID")) h->grid = std::max(1, std::min(h->grid, atoi(e)));  // testing aid
@@ -1316,8 +1327,17 @@ int dfx_conv_submit(dfx_conv_t *h, const void *src_dev, void *dst_dev, dfx_strea
   if (!h->weights_set) return fail(DFX_ERR_STATE, "conv_submit: dfx_conv_set_weights not called");
   DeviceGuard dg(h->device);
   if (h->split0) {
+    // The two launches share the intermediate d_mid: submits of a split op are ordered among each
+    // other, whatever streams they come on -- the first launch of a submit waits (on the device) for
+    // the second launch of the previous one.  Other work on those streams is not held up.
+    std::lock_guard<std::mutex> lk(*h->split_mu);
+    if (h->split_last && h->split_last != (hipStream_t)s) HIP_TRY(hipStreamWaitEvent((hipStream_t)s, h->split_done, 0));
     int rc0 = dfx_conv_submit(h->split0, src_dev, h->d_mid, s);
-    return rc0 != DFX_OK ? rc0 : dfx_conv_submit(h->split1, h->d_mid, dst_dev, s);
+    if (rc0 == DFX_OK) rc0 = dfx_conv_submit(h->split1, h->d_mid, dst_dev, s);
+    if (rc0 != DFX_OK) return rc0;
+    HIP_TRY(hipEventRecord(h->split_done, (hipStream_t)s));
+    h->split_last = (hipStream_t)s;
+    return DFX_OK;
   }
   // per-launch copies: concurrent submits of one handle (other host threads, other streams) share
   // only immutable state and each takes its own unit-queue slot of the ring

@@ -177,9 +177,10 @@ int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei_blocked, const void *b
 /* asynchronous: enqueues on `s`; src_dev/dst_dev are device pointers that must
  * stay valid until the stream reaches the kernel's end.  A handle may be submitted from several
  * host threads and on several streams at once: every launch works on its own copy of the
- * arguments and its own unit-queue slot (up to 16 launches of one handle in flight).  The one
- * exception is an op whose dfx_conv_info.kernel_name starts with "split:" (two launches through
- * a handle-owned intermediate): keep its submits on one stream. */
+ * arguments and its own unit-queue slot (up to 16 launches of one handle in flight).  An op whose
+ * dfx_conv_info.kernel_name starts with "split:" (two launches through a handle-owned
+ * intermediate) may be submitted the same way, but its submits are ordered among each other on the
+ * device: the first launch of one waits for the second launch of the previous one. */
 int dfx_conv_submit(dfx_conv_t *h, const void *src_dev, void *dst_dev, dfx_stream_t s);
 /* drop-in semantics of op::submit() (deepfusion.cc:90-103): host buffers in,
  * host buffers out, synchronous (H2D, kernel, D2H, stream sync). */

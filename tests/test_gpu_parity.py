@@ -517,6 +517,33 @@ def test_repeated_submits_rearm_queue(hip, oracle):
         op.close()
 
 
+def test_concurrent_submits_on_several_streams(hip, oracle):
+    """one handle, launches in flight on four streams at once (include/dfx.h: up to 16 per handle): every
+    launch has its own argument block and queue words, so the outputs must not mix.  Different inputs
+    per launch; the resident-weight kernel (device queue: many units per loader) and a streamed one."""
+    import torch
+    for case in (C.ConvCase("conc_q", 6, 32, 120, 96, 64, 0, dst_dt=C.F32), replace(C.CONFIG3_SMALL, bs=5, dst_dt=C.U8),
+                 C.ConvCase("conc_s", 3, 128, 14, 14, 128, 256, dst_dt=C.S32)):
+        data = C.generate(case)
+        op = hip.make_conv(case, data)
+        rng = np.random.default_rng(11)
+        srcs_np = [rng.integers(0, 256, data["src"].shape).astype(np.uint8) for _ in range(4)]
+        refs = [hip.oracle_conv(oracle, case, dict(data, src=sn)) for sn in srcs_np]
+        streams = [torch.cuda.Stream() for _ in range(4)]
+        tdt = {C.F32: torch.float32, C.S32: torch.int32, C.S8: torch.int8, C.U8: torch.uint8}[case.dst_dt]
+        srcs = [torch.from_numpy(sn).cuda() for sn in srcs_np]
+        outs = [[torch.empty(op.dst_shape, dtype=tdt, device="cuda") for _ in range(3)] for _ in range(4)]
+        torch.cuda.synchronize()
+        for rep in range(3):
+            for i, st in enumerate(streams):
+                op.submit(srcs[i], outs[i][rep], stream=st)
+        torch.cuda.synchronize()
+        for i in range(4):
+            for rep in range(3):
+                hip.assert_bit_equal(outs[i][rep].cpu().numpy(), refs[i], "stream %d launch %d %s" % (i, rep, case.name))
+        op.close()
+
+
 @pytest.mark.parametrize("geom", ["1,56", "2,56", "3,56", "4,56", "3,32", "4,32", "2,32", "7,32"])
 def test_unit_geometries_and_tile_rotation(hip, oracle, geom, tuning):
     """every unit decomposition the host may pick (full-width linear units, 32-multiple
