@@ -11,14 +11,16 @@ case = replace(case, dst_dt=C.U8)
 data = C.generate(case)
 op = hipref.make_conv(case, data)
 src = torch.from_numpy(data["src"]).cuda()
+srcs = [src.clone() for _ in range(4)]
 outs = [torch.empty(op.dst_shape, dtype=torch.uint8, device="cuda") for _ in range(4)]
 for i in range(20): op.submit(src, outs[i % 4])
 torch.cuda.synchronize()
 st = torch.cuda.current_stream()
-for label, kw in (("default stream lookup", {}), ("stream passed", {"stream": st})):
+for label, kw, rot in (("default stream lookup, one src", {}, False), ("stream passed, one src", {"stream": st}, False),
+                       ("stream passed, four srcs rotating", {"stream": st}, True)):
     n = 2000
     t0 = time.perf_counter()
-    for i in range(n): op.submit(src, outs[i % 4], **kw)
+    for i in range(n): op.submit(srcs[i % 4] if rot else src, outs[i % 4], **kw)
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
