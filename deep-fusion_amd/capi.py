@@ -138,7 +138,12 @@ def lib():
         "dfx_debug_set_tuning": (i32, [ctypes.c_char_p, ctypes.c_char_p]),
     }
     for name, (res, args) in sig.items():
-        f = getattr(L, name)
+        try:
+            f = getattr(L, name)
+        except AttributeError:
+            if os.environ.get("DFX_LIB_PATH"):  # an older diagnostic build (A/B against a past round): bind what it has
+                continue
+            raise
         f.restype, f.argtypes = res, args
     _lib = L
     return L
