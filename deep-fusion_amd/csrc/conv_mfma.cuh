@@ -68,10 +68,11 @@
 //    (s32/f32) or G-byte (s8/u8) store per lane and a half-wave writes 128*G (or 32*G)
 //    contiguous bytes: whole HBM lines.
 //
-//  * What bounds the kernel (round 2, profiles/stamps.py timelines): the VALU.  A SIMD issues one
-//    wave64 VALU instruction per 4 cycles, and the u8 epilogue needs two instructions per output value
-//    (v_pk_add_f32 + v_pk_mul_f32 on pixel pairs, one v_cvt_pk_u8_f32 per value): 1 k VALU instructions
-//    per 32-pixel tile against 1.7 k cycles of MFMA.  Hence: no per-pixel address arithmetic in vector
+//  * What bounds the kernel (round 2, profiles/stamps.py timelines, PMC): issue on the SIMD's vector
+//    port, which VALU and MFMA share.  Per 32-pixel tile a wave issues 52 MFMAs (1.7 k matrix-pipe cycles)
+//    and ~576 other VALU instructions at 4 cycles each (the u8 epilogue needs two per output value:
+//    v_pk_add_f32 + v_pk_mul_f32 on pixel pairs, one v_cvt_pk_u8_f32 per value), and the two pipes
+//    mostly alternate (co-execution 17 % of the MFMA-busy cycles).  Hence: no per-pixel address arithmetic in vector
 //    registers (scalar pixel bases + one per-lane offset), no int->float conversions (magic start
 //    values), lane-derived values recomputed instead of spilled (a scratch reload waits for every store
 //    in flight), and the scheduling rules below that keep all four SIMDs fed:
