@@ -28,7 +28,7 @@ class ConvDesc(ctypes.Structure):
         "bs", "ic", "ih", "iw", "oc", "oh", "ow", "kh", "kw", "sh", "sw", "pad_t", "pad_l",
         "oc1x1", "dst_dt", "bia0_dt", "bia1_dt", "conv0_relu", "conv1_relu",
         "conv0_round_mode", "conv1_round_mode", "conv0_nscales", "conv1_nscales",
-        "force_variant")]
+        "force_variant", "fuse_pool")]
 
 
 class ConvInfo(ctypes.Structure):
@@ -189,7 +189,7 @@ class Conv:
     def __init__(self, src_shape_nhwc, wei_shape_oihw, stride=(1, 1), pad=(1, 1), dst_dt=DFX_U8,
                  oc1x1=0, bia0_dt=DFX_UNDEF, bia1_dt=DFX_UNDEF, conv0_relu=False,
                  conv1_relu=False, rm0=ROUND_NEAREST, rm1=ROUND_NEAREST, nscales0=1, nscales1=1,
-                 force_variant=-1):
+                 force_variant=-1, fuse_pool=0):
         bs, ih, iw, ic = src_shape_nhwc
         oc, ic2, kh, kw = wei_shape_oihw
         if ic2 != ic:
@@ -205,10 +205,11 @@ class Conv:
         d.conv0_round_mode, d.conv1_round_mode = rm0, rm1
         d.conv0_nscales, d.conv1_nscales = nscales0, nscales1
         d.force_variant = force_variant
+        d.fuse_pool = fuse_pool
         self.desc = d
         self._h = ctypes.c_void_p()
         _check(lib().dfx_conv_create(ctypes.byref(d), ctypes.byref(self._h)))
-        self.dst_shape = (bs, d.oh, d.ow, oc1x1 if oc1x1 else oc)
+        self.dst_shape = ((bs, d.oh // 2, d.ow // 2, oc) if fuse_pool else (bs, d.oh, d.ow, oc1x1 if oc1x1 else oc))
         self.dst_np_dtype = _NP[dst_dt]
 
     def set_weights(self, wei_blk, scales0, bia0=None, wei1_blk=None, scales1=None, bia1=None):

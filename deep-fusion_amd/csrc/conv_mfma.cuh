@@ -169,6 +169,9 @@ struct MfmaGeom {  // unit decomposition chosen by the host (dfx_api.hip)
   float s0_value;
   int tile_stride;     // bytes between the MFMA_NB input-tile slots in LDS
   int static_rounds;   // units a loader owns statically before it turns to the queue
+  int pool;            // unfused ops only: 1 = 2x2 stride-2 max pooling fused into the store stage.  Units are
+                       // full-width row groups (th even); a tile is 2 rows x 16 columns, so that a pooling
+                       // window is accumulator registers e, e+1, e+8, e+9 of one lane; dst has oh/2 x ow/2 pixels
   int lazy_queue;      // 1: a loader draws its next unit only when the slot for it is free (store-bound ops)
   int *queue;          // [0] next unit, [1] finished loaders; both 0 between launches
 #ifdef DFX_STAMPS
@@ -421,6 +424,86 @@ __device__ __forceinline__ void emit_pair(unsigned char *p0, unsigned char *p1, 
   if (w1) store_pixel<DST, G, MODE != 0>(p1, f1, relu, rm);
 }
 
+// One POOLED pixel: maximum over accumulator registers e, e+1 (two columns of the window's first row) and
+// e+8, e+9 (second row), G consecutive channels -> one store.  The reference's planned op is conv -> relu ->
+// pooling (test/test_conv_relu_pooling.cc:30-235), i.e. the maximum of the four CONVERTED pixels:
+//   integer dst, MODE != 0: relu, nearest-even rounding and saturation are monotonic, so the maximum is taken
+//     on the scaled f32 values and converted once;
+//   f32 dst: relu per pixel, then the pooling kernel's chain acc = acc > x ? acc : x in window order (signed
+//     zeros and the order of equal values as in pool_eltwise.hip);
+//   MODE 0 (x86 overflow / NaN results are not monotonic): every pixel is converted, the maximum is taken on
+//     the converted values.
+template <int DST, int G, int MODE>
+__device__ __forceinline__ void emit_pool(unsigned char *p, const v16i (&acc)[G], int e, const int (&ia)[G],
+                                          const v2f (&fb)[G], const v2f (&fc)[G], bool relu, int rm, bool w) {
+  float f[4][G];
+#pragma unroll
+  for (int c = 0; c < G; ++c)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int r = e + 8 * q;
+      if (MODE == 2) {
+        v2f x = {__int_as_float(acc[c][r]), __int_as_float(acc[c][r + 1])};
+        x = (x + fb[c]) * fc[c];
+        f[2 * q][c] = x[0];
+        f[2 * q + 1][c] = x[1];
+      } else {
+        f[2 * q][c] = __fmul_rn(__fadd_rn(__int2float_rn(acc[c][r] + ia[c]), fb[c][0]), fc[c][0]);
+        f[2 * q + 1][c] = __fmul_rn(__fadd_rn(__int2float_rn(acc[c][r + 1] + ia[c]), fb[c][0]), fc[c][0]);
+      }
+    }
+  if (DST == DFX_F32) {
+    float m[G];
+#pragma unroll
+    for (int c = 0; c < G; ++c) {
+      float accm = -__builtin_inff();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float x = relu ? relu_x86(f[q][c]) : f[q][c];
+        accm = accm > x ? accm : x;
+      }
+      m[c] = accm;
+    }
+    if (w) {
+      if (G == 4) DFX_STORE16(reinterpret_cast<v4f *>(p), (v4f{m[0], m[1], m[2], m[3]}));
+      else if (G == 2) *reinterpret_cast<float2 *>(p) = float2{m[0], m[1]};
+      else *reinterpret_cast<float *>(p) = m[0];
+    }
+  } else if (MODE != 0) {
+    float m[G];
+#pragma unroll
+    for (int c = 0; c < G; ++c) m[c] = __builtin_fmaxf(__builtin_fmaxf(f[0][c], f[1][c]), __builtin_fmaxf(f[2][c], f[3][c]));
+    if (w) store_pixel<DST, G, true>(p, m, relu, rm);
+  } else {
+    int v[G];
+#pragma unroll
+    for (int c = 0; c < G; ++c) {
+      int best = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int x = cvt_x86_rt(relu ? relu_x86(f[q][c]) : f[q][c], rm);
+        const int t = DST == DFX_U8 ? (int)sat_u8_bits_cold(x) : DST == DFX_S8 ? sat_s8(x) : x;
+        best = q == 0 ? t : max(best, t);
+      }
+      v[c] = best;
+    }
+    if (w) {
+      if (DST == DFX_S32) {
+        if (G == 4) DFX_STORE16(reinterpret_cast<v4i *>(p), (v4i{v[0], v[1], v[2], v[3]}));
+        else if (G == 2) *reinterpret_cast<int2 *>(p) = int2{v[0], v[1]};
+        else *reinterpret_cast<int *>(p) = v[0];
+      } else {
+        unsigned pk = 0;
+#pragma unroll
+        for (int c = 0; c < G; ++c) pk |= ((unsigned)v[c] & 0xffu) << (8 * c);
+        if (G == 4) DFX_STORE(reinterpret_cast<unsigned *>(p), pk);
+        else if (G == 2) *reinterpret_cast<unsigned short *>(p) = (unsigned short)pk;
+        else *p = (uint8_t)pk;
+      }
+    }
+  }
+}
+
 // First MFMA of a chain whose accumulator starts from the inline constant 1/(2*pi) (MAGIC1_BITS).
 // Written as asm because hipcc, given the constant as a v16i splat used by several MFMAs,
 // materialises it in 16 VGPRs per use instead of the inline operand.  hipcc does not look into
@@ -506,8 +589,9 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
     unit_split(unit, n, uyi, uxi);
     const int y0 = uyi * g.th, x0 = uxi * g.tw;
     const int th = min(g.th, a.oh - y0), tw = min(g.tw, a.ow - x0);
-    const int tpr = (tw + 31) >> 5;
-    pix0 = (n * a.oh + y0) * a.ow + x0;
+    const int tpr = g.pool ? (tw + 15) >> 4 : (tw + 31) >> 5;
+    pix0 = g.pool ? (n * (a.oh >> 1) + (y0 >> 1)) * (a.ow >> 1) + (x0 >> 1)  // first POOLED pixel of the unit
+                  : (n * a.oh + y0) * a.ow + x0;
     thtw = (th << 16) | tw;
     tprm = tpr > 1 ? (int)(((1ull << 32) + tpr - 1) / tpr) : 0;
   };
@@ -954,7 +1038,8 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
     const int th = thtw >> 16, tw = thtw & 0xffff;
     const int npx = th * tw;
     const int tiles_per_row = (tw + 31) >> 5;
-    const int ntiles = g.linear ? (npx + 31) >> 5 : th * tiles_per_row;
+    const int tiles_per_row16 = (tw + 15) >> 4;  // pooled ops: tiles of 2 rows x 16 columns
+    const int ntiles = g.pool ? (th >> 1) * tiles_per_row16 : g.linear ? (npx + 31) >> 5 : th * tiles_per_row;
 
     DFX_TRACE_AT(6, pix0, ntiles);
     if (ti_now < ntiles) {
@@ -967,7 +1052,14 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
       // pixel of this lane (conv0 column) and the tile's output base (wave-uniform)
       int ty, tx, nvalid;
       size_t obase;  // dst pixel index of px_local == 0
-      if (g.linear) {
+      if (g.pool) {  // nvalid = valid COLUMNS of the 16-column block
+        const int tprm = __builtin_amdgcn_readfirstlane(info[2]);
+        const int tr = tprm ? (int)__umulhi((unsigned)ti_now, (unsigned)tprm) : ti_now, tc = ti_now - tr * tiles_per_row16;
+        nvalid = min(16, tw - 16 * tc);
+        ty = 2 * tr + (l31 >> 4);
+        tx = 16 * tc + min(l31 & 15, nvalid - 1);
+        obase = (size_t)pix0 + (size_t)tr * (a.ow >> 1) + 8 * tc;  // pooled pixel index
+      } else if (g.linear) {
         nvalid = min(32, npx - 32 * ti_now);
         const int pc = 32 * ti_now + min(l31, nvalid - 1);
         ty = tw == 1 ? pc : (int)__umulhi((unsigned)pc, g.tw_magic);  // tw == g.tw in linear mode
@@ -1084,10 +1176,24 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
             emit_pair<DST, G, decltype(mode_tag)::value>(p0, p1, acc0, e, ia, fb, fc, relu1, a.rm0, w0, w1);
           }
         };
+        // fused 2x2/2 max pooling: pooled column 4*((e>>2)&1) + 2h + ((e&3)>>1) of the tile's 8, from registers
+        // e, e+1, e+8, e+9 (e = 0, 2, 4, 6); a pooled pixel exists when both of its columns do
+        auto emit0p = [&](auto mode_tag) {
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            const int pcl = 4 * ((e >> 2) & 1) + ((e & 3) >> 1) + (h4 >> 1);
+            const bool w = 2 * pcl + 1 < nvalid;
+            unsigned char *p = tile_dst + ((unsigned)min(pcl, max(0, (nvalid >> 1) - 1)) * row_bytes + ch_off);
+            emit_pool<DST, G, decltype(mode_tag)::value>(p, acc0, e, ia, fb, fc, relu1, a.rm0, w);
+          }
+        };
         using M0 = std::integral_constant<int, 0>;
         using M1 = std::integral_constant<int, 1>;
         using M2 = std::integral_constant<int, 2>;
-        if (mode0 == 2) { if (nvalid == 32) emit0(M2{}, F{}); else emit0(M2{}, T{}); }
+        if (g.pool) {
+          if (mode0 == 2) emit0p(M2{}); else if (mode0 == 1) emit0p(M1{}); else emit0p(M0{});
+        }
+        else if (mode0 == 2) { if (nvalid == 32) emit0(M2{}, F{}); else emit0(M2{}, T{}); }
         else if (mode0 == 1) { if (nvalid == 32) emit0(M1{}, F{}); else emit0(M1{}, T{}); }
         else { if (nvalid == 32) emit0(M0{}, F{}); else emit0(M0{}, T{}); }
       } else {

@@ -398,6 +398,21 @@ static bool pick_geometry(const dfx_conv_desc &d, MfmaGeom &g, int &lds) {
       g.th = fth; g.tw = ftw; g.linear = ftw == d.ow;
     }
   }
+  g.pool = d.fuse_pool ? 1 : 0;
+  if (g.pool) {
+    // pooled ops: the scored unit (full-width rows, or a 32-multiple of columns) with an even number of rows
+    // (a tile is 2 rows x 16 columns): the largest even th <= the scored one whose tile fits, at least 2
+    auto tile_of = [&](int th, int tw) { return ((size_t)(th + 2) * (tw + 2) * (d.ic / 16) + 63) / 64 * 1024 + 1024; };
+    int th = std::max(2, g.th & ~1);
+    while (th > 2 && tile_of(th, g.tw) > tile_max) th -= 2;
+    if (tile_of(th, g.tw) > tile_max) {  // rows of this width do not fit even in pairs: split the columns
+      g.tw = 32 * std::max(1, std::min(d.ow / 32, 4));
+      g.linear = g.tw == d.ow;
+      while (g.tw > 32 && tile_of(th, g.tw) > tile_max) g.tw -= 32;
+      if (tile_of(th, g.tw) > tile_max) return false;
+    }
+    g.th = th;
+  }
   g.uy = (d.oh + g.th - 1) / g.th;
   g.ux = (d.ow + g.tw - 1) / g.tw;
   g.total_units = d.bs * g.uy * g.ux;
@@ -408,7 +423,8 @@ static bool pick_geometry(const dfx_conv_desc &d, MfmaGeom &g, int &lds) {
   g.tw_magic = (unsigned)(((1ull << 32) + g.tw - 1) / g.tw);
   g.upi_magic = g.uy * g.ux > 1 ? (unsigned)(((1ull << 32) + g.uy * g.ux - 1) / (g.uy * g.ux)) : 0u;
   g.ux_magic = g.ux > 1 ? (unsigned)(((1ull << 32) + g.ux - 1) / g.ux) : 0u;
-  g.ntu = g.linear ? (g.th * g.tw + 31) / 32 : g.th * (g.tw / 32);  // tile claims per unit
+  g.ntu = g.pool ? (g.th / 2) * ((g.tw + 15) / 16)
+                 : g.linear ? (g.th * g.tw + 31) / 32 : g.th * (g.tw / 32);  // tile claims per unit
   g.ntu_magic = (unsigned)(((1ull << 32) + g.ntu - 1) / g.ntu);
   g.claim_limit = (int)std::min<long long>(0x7ffffff0LL, (long long)g.ntu * ((long long)g.total_units + 4));
   lds = (int)(fixed + (size_t)MFMA_NB * g.tile_stride);
@@ -646,6 +662,12 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
 
   bool want_mfma = mfma_eligible(d) && d.force_variant != DFX_VARIANT_GENERIC &&
                    d.force_variant != DFX_VARIANT_MFMA_STREAM;
+  if (d.fuse_pool) {  // fused 2x2/2 max pooling: the resident-weight kernel's unfused form only
+    if (d.fuse_pool != 2 || d.oc1x1 != 0 || !want_mfma || (d.oh & 1) || (d.ow & 1)) {
+      conv_release(h);
+      return fail(DFX_ERR_UNSUPPORTED, "conv_create: fused pooling needs an unfused 3x3 stride-1 conv with 32/64 channels and even output size");
+    }
+  }
   if ((d.force_variant == DFX_VARIANT_MFMA_FUSED || d.force_variant == DFX_VARIANT_MFMA_CONV) && !mfma_eligible(d)) {
     conv_release(h);
     return fail(DFX_ERR_UNSUPPORTED, "conv_create: shape not covered by the MFMA variant");
@@ -814,6 +836,9 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     else
       snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_stream_kernel<%d,%d,%d,%d,%s%s>", h->occ, h->G, h->pxb,
                d.dst_dt, d.oc1x1 ? "fused" : "unfused", h->sgeom.occ_par ? ",occ_par" : "");
+  } else if (d.fuse_pool && !(want_mfma && pick_geometry(d, h->geom, h->lds))) {
+    conv_release(h);  // (no other kernel knows about the pooled destination)
+    return fail(DFX_ERR_UNSUPPORTED, "conv_create: no unit geometry of the resident-weight kernel fits fused pooling here");
   } else if (want_mfma && pick_geometry(d, h->geom, h->lds)) {
     const bool fused = d.oc1x1 > 0;
     h->variant = fused ? DFX_VARIANT_MFMA_FUSED : DFX_VARIANT_MFMA_CONV;
@@ -1358,7 +1383,8 @@ int dfx_conv_submit(dfx_conv_t *h, const void *src_dev, void *dst_dev, dfx_strea
 
 static size_t conv_src_bytes(const dfx_conv_desc &d) { return (size_t)d.bs * d.ih * d.iw * d.ic; }
 static size_t conv_dst_bytes(const dfx_conv_desc &d) {
-  return (size_t)d.bs * d.oh * d.ow * (d.oc1x1 ? d.oc1x1 : d.oc) * dt_size(d.dst_dt);
+  const size_t px = d.fuse_pool ? (size_t)(d.oh / 2) * (d.ow / 2) : (size_t)d.oh * d.ow;
+  return (size_t)d.bs * px * (d.oc1x1 ? d.oc1x1 : d.oc) * dt_size(d.dst_dt);
 }
 
 int dfx_conv_submit_host(dfx_conv_t *h, const void *src_host, void *dst_host) {

@@ -646,6 +646,19 @@ public:
     d.conv0_nscales = (int)scales_.size();
     d.conv1_nscales = 1;
     d.force_variant = -1;
+    // 2x2 stride-2 pooling without padding over an even-sized conv output: fused into the conv kernel's
+    // store stage where that kernel covers the conv (dfx.h, dfx_conv_desc::fuse_pool); one launch, the
+    // unpooled activation never exists
+    if (pk[0] == 2 && pk[1] == 2 && ps[0] == 2 && ps[1] == 2 && pp[0] == 0 && pp[1] == 0 && ch % 2 == 0 && cw % 2 == 0 &&
+        o[2] == ch / 2 && o[3] == cw / 2) {
+      dfx_conv_desc df = d;
+      df.fuse_pool = 2;
+      if (dfx_conv_create(&df, &conv_) == DFX_OK) {
+        st_.ensure_stream();
+        return;
+      }
+      conv_ = nullptr;
+    }
     if (dfx_conv_create(&d, &conv_) != DFX_OK) error_and_exit("Init ConvReluPool op failed! (%s)", dfx_last_error());
     dfx_pool_desc p;
     memset(&p, 0, sizeof(p));
@@ -659,8 +672,8 @@ public:
   }
   ~op_conv_pool() override {
     dfx_conv_destroy(conv_);
-    dfx_pool_destroy(pool_);
-    dfx_mem_free_device(mid_);
+    if (pool_) dfx_pool_destroy(pool_);
+    if (mid_) dfx_mem_free_device(mid_);
   }
   void submit() override {
     run(true);
@@ -692,8 +705,12 @@ protected:
     void *s = st_.sync_in(*src_, sync_host);
     void *o = st_.device_out(*dst_);
     st_.profile_begin();
-    check_dfx(dfx_conv_submit(conv_, s, mid_, st_.stream), "conv submit");
-    check_dfx(dfx_pool_submit(pool_, mid_, o, st_.stream), "pool submit");
+    if (!pool_) {  // pooling fused into the conv kernel
+      check_dfx(dfx_conv_submit(conv_, s, o, st_.stream), "conv submit");
+    } else {
+      check_dfx(dfx_conv_submit(conv_, s, mid_, st_.stream), "conv submit");
+      check_dfx(dfx_pool_submit(pool_, mid_, o, st_.stream), "pool submit");
+    }
     st_.profile_end(name());
   }
   const char *name() override { return "conv_relu_pool"; }

@@ -156,6 +156,27 @@ int main(int argc, char **argv) {
     dump(out + "/pool_b0.bin", bia->host_data(), bia->buffer_size());
     dump(out + "/pool_dst.bin", dst->data(), dst->buffer_size());
   }
+  // ---- the same op on an even-sized conv output, 64 channels: the pooling is fused into the conv kernel ----
+  {
+    const int bs = 2, ic = 64, ih = 12, iw = 40, oc = 64, ph = 6, pw = 20;
+    std::unique_ptr<memory> src(new memory(memory::nchw_dims{bs, ic, ih, iw}, memory::format::nhwc, memory::dtype::u8));
+    std::unique_ptr<memory> wei(new memory(memory::nchw_dims{oc, ic, 3, 3}, memory::format::OIhw4i16o4i, memory::dtype::s8));
+    std::unique_ptr<memory> bia(new memory(memory::dims{oc}, memory::format::x, memory::dtype::s32));
+    std::unique_ptr<memory> dst(new memory(memory::nchw_dims{bs, oc, ph, pw}, memory::format::nhwc, memory::dtype::u8));
+    uint8_t *s = (uint8_t *)src->data();
+    for (size_t i = 0; i < src->size(); ++i) s[i] = (uint8_t)(g.next() % 64);
+    std::vector<s8> w0(wei->size());
+    for (auto &v : w0) v = (s8)((int)(g.next() % 21) - 10);
+    reorder_weights(w0.data(), wei);
+    int32_t *b0 = (int32_t *)bia->data();
+    for (int i = 0; i < oc; ++i) b0[i] = (int)(g.next() % 201) - 100;
+    auto c = conv_relu_pool(src, wei, bia, {1, 1}, {1, 1}, {2, 2}, {2, 2}, {0, 0}, dst, true, {1.f / 64});
+    c->submit();
+    dump(out + "/poolf_src.bin", src->host_data(), src->buffer_size());
+    dump(out + "/poolf_w0_oihw.bin", w0.data(), w0.size());
+    dump(out + "/poolf_b0.bin", bia->host_data(), bia->buffer_size());
+    dump(out + "/poolf_dst.bin", dst->data(), dst->buffer_size());
+  }
   // ---- eltwise sum + relu of three s8 tensors (roadmap op) ----
   {
     std::vector<std::unique_ptr<memory>> srcs;

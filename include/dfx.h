@@ -75,6 +75,11 @@ typedef struct dfx_conv_desc {
   int32_t conv0_nscales;   /* 1 or oc     (op_conv.cc:311-313) */
   int32_t conv1_nscales;   /* 1 or oc1x1  (op_conv.cc:342-345) */
   int32_t force_variant;   /* -1 = auto, else DFX_VARIANT_* (testing) */
+  int32_t fuse_pool;       /* 0 = none; 2 = 2x2 stride-2 max pooling of the conv's output (after ReLU and
+                              requantisation) fused into the conv kernel: dst then holds {bs, oh/2, ow/2, oc}.
+                              Only for unfused 3x3 stride-1 convs on the resident-weight kernel with even oh, ow;
+                              dfx_conv_create returns DFX_ERR_UNSUPPORTED otherwise (the caller then runs
+                              dfx_pool_* behind an unpooled conv, as deepfusion::conv_relu_pool does). */
 } dfx_conv_desc;
 
 typedef struct dfx_conv_info {

@@ -29,5 +29,7 @@ for (bs, hw, ic, oc) in ((64, 224, 64, 64), (128, 56, 64, 64)):
     def pair(i):
         op.submit(srcs[i % nb], mids[i % nb]); pool.submit(mids[i % nb], outs[i % nb])
     t_pair = timeit(pair)
-    print(json.dumps({"shape": [bs, hw, hw, ic, oc], "intermediate_MB": round(mids[0].numel() / 1e6, 1), "conv_ms": round(t_conv, 5), "pool_cold_ms": round(t_pool, 5),
+    fop = hipref.make_conv(case, data, fuse_pool=2)
+    t_fused = timeit(lambda i: fop.submit(srcs[i % nb], outs[i % nb]))
+    print(json.dumps({"shape": [bs, hw, hw, ic, oc], "fused_ms": round(t_fused, 5), "fused_kernel": fop.info().kernel_name.decode(), "intermediate_MB": round(mids[0].numel() / 1e6, 1), "conv_ms": round(t_conv, 5), "pool_cold_ms": round(t_pool, 5),
                       "pair_ms": round(t_pair, 5), "pool_behind_conv_ms": round(t_pair - t_conv, 5)}))

@@ -20,8 +20,8 @@ def oracle_conv(orc, case, data, impl=None):
                     relu1=case.relu1, rm0=case.rm0, rm1=case.rm1, impl=impl)
 
 
-def make_conv(case, data, force_variant=-1):
-    op = dfa.Conv(data["src"].shape, data["w0"].shape, stride=case.stride, pad=case.pad,
+def make_conv(case, data, force_variant=-1, fuse_pool=0):
+    op = dfa.Conv(data["src"].shape, data["w0"].shape, stride=case.stride, pad=case.pad, fuse_pool=fuse_pool,
                   dst_dt=case.dst_dt, oc1x1=case.oc1x1, bia0_dt=case.bia0_dt,
                   bia1_dt=case.bia1_dt if case.oc1x1 else 0, conv0_relu=case.relu0,
                   conv1_relu=case.relu1, rm0=case.rm0, rm1=case.rm1,

@@ -463,6 +463,57 @@ def test_maxpool_and_eltwise_sum(hip, oracle):
         hip.dfa.Pool(1, 16, 4, 4, 4, 4, (2, 2), (2, 2), (0, 0), np.uint8)
 
 
+POOL_FUSED_CASES = [
+    # unfused 3x3 stride-1 convs with even output sizes: widths that are / are not multiples of 16, one and
+    # two 32-channel blocks, every dst type, both requant routes (reference-range and wide weights), round down
+    C.ConvCase("pf_u8", 3, 64, 12, 40, 64, 0, dst_dt=C.U8),
+    C.ConvCase("pf_u8w", 2, 32, 8, 56, 64, 0, dst_dt=C.U8, wide=True),
+    C.ConvCase("pf_s8", 2, 64, 6, 18, 32, 0, dst_dt=C.S8, relu0=False),
+    C.ConvCase("pf_s32", 2, 32, 10, 34, 32, 0, dst_dt=C.S32, relu0=False),
+    C.ConvCase("pf_f32", 2, 64, 14, 14, 64, 0, dst_dt=C.F32, relu0=False, per_channel0=True),
+    C.ConvCase("pf_f32r", 5, 32, 4, 100, 64, 0, dst_dt=C.F32),
+    C.ConvCase("pf_rd", 2, 64, 8, 24, 64, 0, dst_dt=C.U8, rm0=1, wide=True),
+    C.ConvCase("pf_np", 2, 32, 10, 10, 32, 0, dst_dt=C.U8, pad=(0, 0)),
+    C.ConvCase("pf_big", 9, 64, 56, 56, 64, 0, dst_dt=C.U8),
+    C.ConvCase("pf_wide", 2, 64, 8, 224, 64, 0, dst_dt=C.U8),          # rows too wide for LDS: column-split units
+    C.ConvCase("pf_w200", 1, 32, 6, 200, 32, 0, dst_dt=C.S32, relu0=False),
+    C.ConvCase("pf_w72", 2, 64, 4, 72, 32, 0, dst_dt=C.S8),
+]
+
+
+@pytest.mark.parametrize("case", POOL_FUSED_CASES, ids=lambda c: c.ident())
+def test_conv_with_fused_max_pool(hip, oracle, tuning, case):
+    """dfx_conv_desc::fuse_pool = 2: the conv kernel's store stage takes the 2x2 maximum (tiles of 2 rows x 16
+    columns); must equal oracle conv -> oracle 2x2/2 max pooling bit for bit, in every requant mode."""
+    import torch
+    data = C.generate(case)
+    mid = hip.oracle_conv(oracle, case, data)
+    ref = oracle.maxpool(mid, (2, 2), (2, 2), (0, 0), (mid.shape[1] // 2, mid.shape[2] // 2))
+    for switch in (None, "DFX_NO_MAGIC", "DFX_NO_FAST"):
+        if switch:
+            tuning.setenv(switch, "1")
+        op = hip.make_conv(case, data, fuse_pool=2)
+        tuning.undo()
+        assert op.dst_shape == ref.shape
+        src = torch.from_numpy(data["src"]).cuda()
+        tdt = {C.F32: torch.float32, C.S32: torch.int32, C.S8: torch.int8, C.U8: torch.uint8}[case.dst_dt]
+        dst = torch.empty(op.dst_shape, dtype=tdt, device="cuda")
+        dst.view(torch.uint8).fill_(0xCD)
+        op.submit(src, dst)
+        torch.cuda.synchronize()
+        hip.assert_bit_equal(dst.cpu().numpy(), ref, "fused pool %s %s" % (case.name, switch))
+        op.close()
+
+
+def test_fused_pool_is_refused_where_unsupported(hip):
+    with pytest.raises(hip.dfa.DfxError):   # odd conv output size
+        hip.dfa.Conv((1, 11, 9, 32), (32, 32, 3, 3), fuse_pool=2)
+    with pytest.raises(hip.dfa.DfxError):   # fused 1x1 stage
+        hip.dfa.Conv((1, 8, 8, 32), (32, 32, 3, 3), oc1x1=64, fuse_pool=2)
+    with pytest.raises(hip.dfa.DfxError):   # not on the resident-weight kernel
+        hip.dfa.Conv((1, 8, 8, 128), (128, 128, 3, 3), fuse_pool=2)
+
+
 def test_concat_golden(hip):
     import torch
     for np_dt in (np.float32, np.int32, np.int8, np.uint8):
