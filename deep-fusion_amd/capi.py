@@ -253,9 +253,11 @@ class Conv:
 class Pool:
     """dfx_pool_* handle: the pooling stage of the reference's planned conv+relu+pool op (max pooling, NHWC)."""
 
-    def __init__(self, bs, c, ih, iw, oh, ow, kernel, stride, pad, np_dtype):
+    MAX, AVG_INCLUDE_PADDING, AVG_EXCLUDE_PADDING = 0, 1, 2
+
+    def __init__(self, bs, c, ih, iw, oh, ow, kernel, stride, pad, np_dtype, algo=0):
         d = PoolDesc(bs, c, ih, iw, oh, ow, kernel[0], kernel[1], stride[0], stride[1], pad[0], pad[1],
-                     _DT[np.dtype(np_dtype)], 0)
+                     _DT[np.dtype(np_dtype)], algo)
         self.dst_shape = (bs, oh, ow, c)
         self._h = ctypes.c_void_p()
         _check(lib().dfx_pool_create(ctypes.byref(d), ctypes.byref(self._h)))

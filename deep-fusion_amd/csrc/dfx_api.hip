@@ -1593,7 +1593,7 @@ int dfx_pool_create(const dfx_pool_desc *desc, dfx_pool_t **out) {
       d.sh <= 0 || d.sw <= 0 || d.pad_t < 0 || d.pad_l < 0)
     return fail(DFX_ERR_INVALID, "pool: bad dimension");
   if (d.dt < DFX_F32 || d.dt > DFX_U8) return fail(DFX_ERR_INVALID, "pool: bad dtype");
-  if (d.algo != DFX_POOL_MAX) return fail(DFX_ERR_UNSUPPORTED, "pool: only max pooling is implemented");
+  if (d.algo < DFX_POOL_MAX || d.algo > DFX_POOL_AVG_EXCLUDE_PADDING) return fail(DFX_ERR_INVALID, "pool: bad algorithm");
   // every output window must contain at least one input position (as MKL-DNN requires)
   if (d.pad_t >= d.kh || d.pad_l >= d.kw || (long long)(d.oh - 1) * d.sh - d.pad_t >= d.ih ||
       (long long)(d.ow - 1) * d.sw - d.pad_l >= d.iw)
@@ -1609,6 +1609,7 @@ int dfx_pool_create(const dfx_pool_desc *desc, dfx_pool_t **out) {
   memset(&a, 0, sizeof(a));
   a.bs = d.bs; a.c = d.c; a.ih = d.ih; a.iw = d.iw; a.oh = d.oh; a.ow = d.ow;
   a.kh = d.kh; a.kw = d.kw; a.sh = d.sh; a.sw = d.sw; a.pad_t = d.pad_t; a.pad_l = d.pad_l; a.dt = d.dt;
+  a.algo = d.algo;
   const size_t es = dt_size(d.dt);
   a.vec = ((size_t)d.c * es) % 16 == 0;
   a.groups = a.vec ? (int)((size_t)d.c * es / 16) : d.c;

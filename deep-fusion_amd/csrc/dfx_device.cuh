@@ -114,6 +114,7 @@ struct PoolArgs {
   const unsigned char *src;
   unsigned char *dst;
   int bs, c, ih, iw, oh, ow, kh, kw, sh, sw, pad_t, pad_l, dt;
+  int algo;             // dfx_pool_algo
   int vec;              // 1: one 16-byte channel group per thread (c * element size a multiple of 16)
   int groups;           // work items per output pixel
   long long total;      // work items

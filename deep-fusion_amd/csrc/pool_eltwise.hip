@@ -53,12 +53,72 @@ __device__ __forceinline__ void pool_item(const PoolArgs &a, long long id) {
   else q[0] = acc[0];
 }
 
+// average pooling: integer types sum exactly (the window is small: int is wide enough for 1-byte types,
+// long long for s32), then float(sum) / float(count) -> nearest even -> saturation; f32 sums in window order
+template <typename T> struct AvgAcc { typedef int type; };
+template <> struct AvgAcc<int> { typedef long long type; };
+template <> struct AvgAcc<float> { typedef float type; };
+template <typename T>
+__device__ __forceinline__ T avg_finish(typename AvgAcc<T>::type sum, int count);
+template <> __device__ __forceinline__ float avg_finish<float>(float sum, int count) { return __fdiv_rn(sum, (float)count); }
+template <> __device__ __forceinline__ int avg_finish<int>(long long sum, int count) {
+  const float q = __builtin_rintf(__fdiv_rn((float)sum, (float)count));
+  return q >= 2147483648.0f ? 2147483647 : q <= -2147483648.0f ? (int)0x80000000 : (int)q;
+}
+template <> __device__ __forceinline__ signed char avg_finish<signed char>(int sum, int count) {
+  return (signed char)min(127, max(-128, (int)__builtin_rintf(__fdiv_rn((float)sum, (float)count))));
+}
+template <> __device__ __forceinline__ unsigned char avg_finish<unsigned char>(int sum, int count) {
+  return (unsigned char)min(255, max(0, (int)__builtin_rintf(__fdiv_rn((float)sum, (float)count))));
+}
+
+template <typename T, int N>
+__device__ __forceinline__ void avgpool_item(const PoolArgs &a, long long id) {
+  const long long px = id / a.groups;
+  const int g = (int)(id - px * a.groups);
+  const int ox = (int)(px % a.ow);
+  const long long t = px / a.ow;
+  const int oy = (int)(t % a.oh), n = (int)(t / a.oh);
+  typename AvgAcc<T>::type acc[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) acc[e] = 0;
+  const int y0 = oy * a.sh - a.pad_t, x0 = ox * a.sw - a.pad_l;
+  int inside = 0;
+  for (int ky = 0; ky < a.kh; ++ky) {
+    const int y = y0 + ky;
+    if (y < 0 || y >= a.ih) continue;
+    for (int kx = 0; kx < a.kw; ++kx) {
+      const int x = x0 + kx;
+      if (x < 0 || x >= a.iw) continue;
+      const T *p = reinterpret_cast<const T *>(a.src) + (((size_t)n * a.ih + y) * a.iw + x) * a.c + (size_t)g * N;
+      T v[N];
+      if (N * sizeof(T) == 16) *reinterpret_cast<v4i *>(v) = *reinterpret_cast<const v4i *>(p);
+      else v[0] = p[0];
+#pragma unroll
+      for (int e = 0; e < N; ++e) acc[e] = acc[e] + (typename AvgAcc<T>::type)v[e];
+      ++inside;
+    }
+  }
+  const int count = a.algo == DFX_POOL_AVG_INCLUDE_PADDING ? a.kh * a.kw : inside;
+  T out[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) out[e] = avg_finish<T>(acc[e], count);
+  T *q = reinterpret_cast<T *>(a.dst) + (size_t)px * a.c + (size_t)g * N;
+  if (N * sizeof(T) == 16) dfx_store16(reinterpret_cast<v4i *>(q), *reinterpret_cast<const v4i *>(out));
+  else q[0] = out[0];
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x; id < a.total; id += stride) {
-    if (a.vec) pool_item<T, 16 / (int)sizeof(T)>(a, id);
-    else pool_item<T, 1>(a, id);
+    if (a.algo == DFX_POOL_MAX) {
+      if (a.vec) pool_item<T, 16 / (int)sizeof(T)>(a, id);
+      else pool_item<T, 1>(a, id);
+    } else {
+      if (a.vec) avgpool_item<T, 16 / (int)sizeof(T)>(a, id);
+      else avgpool_item<T, 1>(a, id);
+    }
   }
 }
 

@@ -614,7 +614,7 @@ public:
   op_conv_pool(const std::unique_ptr<memory> &src, const std::unique_ptr<memory> &wei,
                const std::unique_ptr<memory> &bia, std::array<int, 2> stride, std::array<int, 2> pad,
                std::array<int, 2> pk, std::array<int, 2> ps, std::array<int, 2> pp, std::unique_ptr<memory> &dst,
-               bool relu, const std::vector<float> &scales, round_mode rm)
+               bool relu, const std::vector<float> &scales, round_mode rm, pool_algo algo)
       : src_(src.get()), wei_(wei.get()), bia_(bia.get()), dst_(dst.get()), scales_(scales), conv_(nullptr),
         pool_(nullptr), mid_(nullptr), wei_seen_(0) {
     using fmt = memory::format;
@@ -649,7 +649,7 @@ public:
     // 2x2 stride-2 pooling without padding over an even-sized conv output: fused into the conv kernel's
     // store stage where that kernel covers the conv (dfx.h, dfx_conv_desc::fuse_pool); one launch, the
     // unpooled activation never exists
-    if (pk[0] == 2 && pk[1] == 2 && ps[0] == 2 && ps[1] == 2 && pp[0] == 0 && pp[1] == 0 && ch % 2 == 0 && cw % 2 == 0 &&
+    if (algo == pool_algo::max && pk[0] == 2 && pk[1] == 2 && ps[0] == 2 && ps[1] == 2 && pp[0] == 0 && pp[1] == 0 && ch % 2 == 0 && cw % 2 == 0 &&
         o[2] == ch / 2 && o[3] == cw / 2) {
       dfx_conv_desc df = d;
       df.fuse_pool = 2;
@@ -665,7 +665,8 @@ public:
     p.bs = s[0]; p.c = w[0]; p.ih = ch; p.iw = cw; p.oh = o[2]; p.ow = o[3];
     p.kh = pk[0]; p.kw = pk[1]; p.sh = ps[0]; p.sw = ps[1]; p.pad_t = pp[0]; p.pad_l = pp[1];
     p.dt = d.dst_dt;
-    p.algo = DFX_POOL_MAX;
+    p.algo = algo == pool_algo::max ? DFX_POOL_MAX
+           : algo == pool_algo::avg_include_padding ? DFX_POOL_AVG_INCLUDE_PADDING : DFX_POOL_AVG_EXCLUDE_PADDING;
     if (dfx_pool_create(&p, &pool_) != DFX_OK) error_and_exit("Init ConvReluPool op failed! (%s)", dfx_last_error());
     check_dfx(dfx_mem_alloc_device(&mid_, (size_t)s[0] * ch * cw * w[0] * dtype_size(dst_->data_type())), "device alloc");
     st_.ensure_stream();
@@ -780,9 +781,9 @@ std::unique_ptr<op> conv_relu_pool(const std::unique_ptr<memory> &src, const std
                                    std::array<int, 2> conv_padding, std::array<int, 2> pool_kernel,
                                    std::array<int, 2> pool_stride, std::array<int, 2> pool_padding,
                                    std::unique_ptr<memory> &dst, bool conv_relu, std::vector<float> conv_scales,
-                                   round_mode conv_round_mode) {
+                                   round_mode conv_round_mode, pool_algo algo) {
   return std::unique_ptr<op>(new op_conv_pool(src, wei, bia, conv_stride, conv_padding, pool_kernel, pool_stride,
-                                              pool_padding, dst, conv_relu, conv_scales, conv_round_mode));
+                                              pool_padding, dst, conv_relu, conv_scales, conv_round_mode, algo));
 }
 
 std::unique_ptr<op> eltwise_sum(const std::vector<std::unique_ptr<memory>> &srcs, std::unique_ptr<memory> &dst,

@@ -177,6 +177,29 @@ int main(int argc, char **argv) {
     dump(out + "/poolf_b0.bin", bia->host_data(), bia->buffer_size());
     dump(out + "/poolf_dst.bin", dst->data(), dst->buffer_size());
   }
+  // ---- 1x1 conv + relu + 7x7 global average (exclude padding): the ResNet-head instance of
+  //      test_conv_relu_pooling.cc:334-335, scaled to 64 -> 128 channels ----
+  {
+    const int bs = 3, ic = 64, ih = 7, iw = 7, oc = 128;
+    std::unique_ptr<memory> src(new memory(memory::nchw_dims{bs, ic, ih, iw}, memory::format::nhwc, memory::dtype::u8));
+    std::unique_ptr<memory> wei(new memory(memory::nchw_dims{oc, ic, 1, 1}, memory::format::OIhw4i16o4i, memory::dtype::s8));
+    std::unique_ptr<memory> bia(new memory(memory::dims{oc}, memory::format::x, memory::dtype::s32));
+    std::unique_ptr<memory> dst(new memory(memory::nchw_dims{bs, oc, 1, 1}, memory::format::nhwc, memory::dtype::u8));
+    uint8_t *s = (uint8_t *)src->data();
+    for (size_t i = 0; i < src->size(); ++i) s[i] = (uint8_t)(g.next() % 200);
+    std::vector<s8> w0(wei->size());
+    for (auto &v : w0) v = (s8)((int)(g.next() % 15) - 7);
+    reorder_weights(w0.data(), wei);
+    int32_t *b0 = (int32_t *)bia->data();
+    for (int i = 0; i < oc; ++i) b0[i] = (int)(g.next() % 2001) - 1000;
+    auto c = conv_relu_pool(src, wei, bia, {1, 1}, {0, 0}, {7, 7}, {7, 7}, {0, 0}, dst, true, {1.f / 64},
+                            round_mode::nearest, pool_algo::avg_exclude_padding);
+    c->submit();
+    dump(out + "/avg_src.bin", src->host_data(), src->buffer_size());
+    dump(out + "/avg_w0_oihw.bin", w0.data(), w0.size());
+    dump(out + "/avg_b0.bin", bia->host_data(), bia->buffer_size());
+    dump(out + "/avg_dst.bin", dst->data(), dst->buffer_size());
+  }
   // ---- eltwise sum + relu of three s8 tensors (roadmap op) ----
   {
     std::vector<std::unique_ptr<memory>> srcs;

@@ -178,6 +178,11 @@ std::unique_ptr<op> conv(const std::unique_ptr<memory> &src,
 // planned one in test/test_conv_relu_pooling.cc:264-281; semantics of the MKL-DNN pipeline that test
 // builds (:30-235): conv (+bias, scale, round) -> relu -> max pooling whose padding takes no part.
 // `dst` carries the pooled dims; the conv output dims follow from src / wei / stride / padding. ----
+enum class pool_algo {  // the reference test's max_pooling / pooling_avg_* flags (test_conv_relu_pooling.cc:189-193)
+  max = 0,
+  avg_include_padding,
+  avg_exclude_padding,
+};
 std::unique_ptr<op> conv_relu_pool(const std::unique_ptr<memory> &src,
                                    const std::unique_ptr<memory> &wei,
                                    const std::unique_ptr<memory> &bia,
@@ -189,7 +194,8 @@ std::unique_ptr<op> conv_relu_pool(const std::unique_ptr<memory> &src,
                                    std::unique_ptr<memory> &dst,
                                    bool conv_relu = true,
                                    std::vector<float> conv_scales = {1.f},
-                                   round_mode conv_round_mode = round_mode::nearest);
+                                   round_mode conv_round_mode = round_mode::nearest,
+                                   pool_algo algo = pool_algo::max);
 
 // dst = relu?(saturate(sum of srcs)): same shape, format and dtype everywhere; integer sums are
 // exact and saturate to the dtype's range, f32 sums run left to right (README.md:65, the "shortcut

@@ -107,7 +107,11 @@ typedef struct dfx_concat dfx_concat_t;
  *      "eltwise-sum + relu fused op"; planned signature in test/test_conv_relu_pooling.cc:264-281).
  *      The reference ships no implementation: semantics follow the MKL-DNN pipeline its test
  *      builds (test_conv_relu_pooling.cc:30-235).  Parity unpinned. ---- */
-typedef enum dfx_pool_algo { DFX_POOL_MAX = 0 } dfx_pool_algo;
+typedef enum dfx_pool_algo {
+  DFX_POOL_MAX = 0,
+  DFX_POOL_AVG_INCLUDE_PADDING = 1,  /* sum over the window's positions inside the input / (kh * kw) */
+  DFX_POOL_AVG_EXCLUDE_PADDING = 2   /* ... / number of those positions */
+} dfx_pool_algo;
 typedef struct dfx_pool_desc {
   int32_t bs, c, ih, iw;    /* NHWC input (the conv's output) */
   int32_t oh, ow;           /* given by the caller like the reference's dst_dims; windows may hang over the
@@ -115,7 +119,11 @@ typedef struct dfx_pool_desc {
   int32_t kh, kw, sh, sw, pad_t, pad_l;
   int32_t dt;               /* dfx_dtype of src and dst */
   int32_t algo;             /* DFX_POOL_MAX: maximum over the window's positions INSIDE the input
-                               (padding does not take part, as in MKL-DNN's pooling_max) */
+                               (padding does not take part, as in MKL-DNN's pooling_max).
+                               DFX_POOL_AVG_*: integer types sum exactly, divide in f32 (float(sum) /
+                               float(count)), round to nearest even and saturate to the dtype; f32 sums in
+                               window order and divides (the reference test's pooling_avg_* flags,
+                               test_conv_relu_pooling.cc:189-193; MKL-DNN's reference pooling arithmetic) */
 } dfx_pool_desc;
 typedef struct dfx_pool dfx_pool_t;
 

@@ -302,6 +302,47 @@ int dfo_maxpool(const void *src, void *dst, int bs, int c, int ih, int iw, int o
   return 0;
 }
 
+/* algo 1: average including padding (divisor kh * kw), 2: excluding it (divisor = positions inside the input);
+ * integer types: exact sum, (float)sum / (float)count, nearbyintf (nearest even), saturation; f32: sum in
+ * window order, one division (MKL-DNN reference pooling arithmetic; parity unpinned) */
+int dfo_avgpool(const void *src, void *dst, int bs, int c, int ih, int iw, int oh, int ow, int kh, int kw,
+                int sh, int sw, int pad_t, int pad_l, int dt, int algo) {
+  if (!src || !dst || dt < DFO_F32 || dt > DFO_U8 || (algo != 1 && algo != 2)) return -1;
+  for (int n = 0; n < bs; ++n)
+    for (int oy = 0; oy < oh; ++oy)
+      for (int ox = 0; ox < ow; ++ox)
+        for (int ch = 0; ch < c; ++ch) {
+          float sf = 0.f;
+          long long si = 0;
+          int inside = 0;
+          for (int ky = 0; ky < kh; ++ky) {
+            const int y = oy * sh - pad_t + ky;
+            if (y < 0 || y >= ih) continue;
+            for (int kx = 0; kx < kw; ++kx) {
+              const int x = ox * sw - pad_l + kx;
+              if (x < 0 || x >= iw) continue;
+              const size_t i = (((size_t)n * ih + y) * iw + x) * c + ch;
+              if (dt == DFO_F32) sf = sf + ((const float *)src)[i];
+              else si += dt == DFO_S32 ? ((const int32_t *)src)[i] : dt == DFO_S8 ? ((const int8_t *)src)[i]
+                                                                              : ((const uint8_t *)src)[i];
+              ++inside;
+            }
+          }
+          if (!inside) return -2;
+          const int count = algo == 1 ? kh * kw : inside;
+          const size_t o = (((size_t)n * oh + oy) * ow + ox) * c + ch;
+          if (dt == DFO_F32) {
+            ((float *)dst)[o] = sf / (float)count;
+          } else {
+            const float q = nearbyintf((float)si / (float)count);
+            if (dt == DFO_S32) ((int32_t *)dst)[o] = q >= 2147483648.0f ? INT32_MAX : q <= -2147483648.0f ? INT32_MIN : (int32_t)q;
+            else if (dt == DFO_S8) ((int8_t *)dst)[o] = (int8_t)(q > 127.f ? 127 : q < -128.f ? -128 : (int)q);
+            else ((uint8_t *)dst)[o] = (uint8_t)(q > 255.f ? 255 : q < 0.f ? 0 : (int)q);
+          }
+        }
+  return 0;
+}
+
 int dfo_eltwise_sum(int n_inputs, const void *const *srcs, void *dst, long long elems, int dt, int post_relu) {
   if (!srcs || !dst || n_inputs < 1 || dt < DFO_F32 || dt > DFO_U8) return -1;
   for (long long i = 0; i < elems; ++i) {

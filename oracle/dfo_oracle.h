@@ -108,6 +108,10 @@ int dfo_concat(int n_inputs, const void *const *srcs, const int *channels,
  * lies entirely in the padding. */
 int dfo_maxpool(const void *src, void *dst, int bs, int c, int ih, int iw, int oh, int ow, int kh, int kw,
                 int sh, int sw, int pad_t, int pad_l, int dt);
+/* average pooling: algo 1 = divisor kh * kw (include padding), 2 = positions inside the input; integer types
+ * exact sum, f32 division, nearest-even rounding, saturation (parity unpinned) */
+int dfo_avgpool(const void *src, void *dst, int bs, int c, int ih, int iw, int oh, int ow, int kh, int kw,
+                int sh, int sw, int pad_t, int pad_l, int dt, int algo);
 /* dst = relu?(saturate(sum_k src_k)): integers exact + saturated to the dtype, f32 left to right */
 int dfo_eltwise_sum(int n_inputs, const void *const *srcs, void *dst, long long elems, int dt, int post_relu);
 

@@ -57,6 +57,8 @@ def lib():
                                  ctypes.c_int, vp]
         L.dfo_maxpool.restype = ctypes.c_int
         L.dfo_maxpool.argtypes = [vp, vp] + [ctypes.c_int] * 13
+        L.dfo_avgpool.restype = ctypes.c_int
+        L.dfo_avgpool.argtypes = [vp, vp] + [ctypes.c_int] * 14
         L.dfo_eltwise_sum.restype = ctypes.c_int
         L.dfo_eltwise_sum.argtypes = [ctypes.c_int, ctypes.POINTER(vp), vp, ctypes.c_longlong, ctypes.c_int, ctypes.c_int]
         L.dfo_reorder_oihw_to_blocked.restype = None
@@ -157,6 +159,19 @@ def maxpool(src, kernel, stride, pad, out_hw):
                            pad[0], pad[1], DT_OF[src.dtype])
     if rc != 0:
         raise RuntimeError("oracle maxpool failed with code %d" % rc)
+    return dst
+
+
+def avgpool(src, kernel, stride, pad, out_hw, include_padding):
+    """src: NHWC ndarray; average pooling (divisor kh*kw or the number of positions inside the input)."""
+    src = np.ascontiguousarray(src)
+    bs, ih, iw, c = src.shape
+    oh, ow = out_hw
+    dst = np.zeros((bs, oh, ow, c), dtype=src.dtype)
+    rc = lib().dfo_avgpool(_ptr(src), _ptr(dst), bs, c, ih, iw, oh, ow, kernel[0], kernel[1], stride[0], stride[1],
+                           pad[0], pad[1], DT_OF[src.dtype], 1 if include_padding else 2)
+    if rc != 0:
+        raise RuntimeError("oracle avgpool failed with code %d" % rc)
     return dst
 
 

@@ -82,6 +82,38 @@ def maxpool(src, kernel, stride, pad, out_hw):
     return out
 
 
+def avgpool(src, kernel, stride, pad, out_hw, include_padding):
+    """Independent formulation of NHWC average pooling: zero-padded buffer and a ones mask, both summed over
+    shifted strided views; integer types divide in f32 and round half to even.  (f32: the window-order sum
+    of the oracle equals this shifted-view order: ky outer, kx inner.)"""
+    bs, ih, iw, c = src.shape
+    oh, ow = out_hw
+    need_h = (oh - 1) * stride[0] + kernel[0]
+    need_w = (ow - 1) * stride[1] + kernel[1]
+    is_f = src.dtype == np.float32
+    buf = np.zeros((bs, max(need_h, pad[0] + ih), max(need_w, pad[1] + iw), c), dtype=np.float32 if is_f else np.int64)
+    msk = np.zeros(buf.shape[1:3], dtype=np.int64)
+    buf[:, pad[0]:pad[0] + ih, pad[1]:pad[1] + iw, :] = src
+    msk[pad[0]:pad[0] + ih, pad[1]:pad[1] + iw] = 1
+    tot = np.zeros((bs, oh, ow, c), dtype=buf.dtype)
+    cnt = np.zeros((oh, ow), dtype=np.int64)
+    for ky in range(kernel[0]):
+        for kx in range(kernel[1]):
+            sl = (slice(ky, ky + (oh - 1) * stride[0] + 1, stride[0]), slice(kx, kx + (ow - 1) * stride[1] + 1, stride[1]))
+            m = msk[sl]
+            if is_f:  # skip padded positions entirely (adding +0.0 could turn a -0.0 sum into +0.0)
+                tot = np.where(m[None, :, :, None] == 1, (tot + buf[(slice(None),) + sl]).astype(np.float32), tot)
+            else:
+                tot = tot + buf[(slice(None),) + sl]
+            cnt = cnt + m
+    div = np.full((oh, ow), kernel[0] * kernel[1], dtype=np.int64) if include_padding else cnt
+    if is_f:
+        return (tot / div[None, :, :, None].astype(np.float32)).astype(np.float32)
+    q = np.rint(tot.astype(np.float32) / div[None, :, :, None].astype(np.float32))
+    info = np.iinfo(src.dtype)
+    return np.clip(q, info.min, info.max).astype(src.dtype)
+
+
 def eltwise_sum(srcs, post_relu=False):
     """Independent formulation: exact integer sum in int64 (f32: left to right in f32), clip, relu."""
     if srcs[0].dtype == np.float32:

@@ -82,6 +82,13 @@ def test_dropin_cpp_api(oracle, tmp_path):
                       np.array([1.0 / 64], dtype=np.float32), bia0=b0, relu0=True)
     ref = oracle.maxpool(mid, (2, 2), (2, 2), (0, 0), (6, 20))
     assert np.array_equal(_load(d, "poolf_dst.bin", np.uint8, ref.shape), ref)
+    src = _load(d, "avg_src.bin", np.uint8, (3, 7, 7, 64))          # 1x1 conv + relu + 7x7 global average
+    w0 = _load(d, "avg_w0_oihw.bin", np.int8, (128, 64, 1, 1))
+    b0 = _load(d, "avg_b0.bin", np.int32)
+    mid = oracle.conv(src, oracle.reorder_oihw_to_blocked(w0), w0.shape, (1, 1), (0, 0), C.U8,
+                      np.array([1.0 / 64], dtype=np.float32), bia0=b0, relu0=True)
+    ref = oracle.avgpool(mid, (7, 7), (7, 7), (0, 0), (1, 1), False)
+    assert np.array_equal(_load(d, "avg_dst.bin", np.uint8, ref.shape), ref)
     srcs = [_load(d, "elt_s8_src%d.bin" % k, np.int8, (2, 5, 7, 24)) for k in range(3)]
     ref = oracle.eltwise_sum(srcs, True)
     assert np.array_equal(_load(d, "elt_s8_dst.bin", np.int8, ref.shape), ref)

@@ -448,6 +448,14 @@ def test_maxpool_and_eltwise_sum(hip, oracle):
             torch.cuda.synchronize()
             hip.assert_bit_equal(dst.cpu().numpy(), oracle.maxpool(x, k, s, p, o), "maxpool %s %s" % (shape, np_dt))
             op.close()
+            for algo, inc in ((hip.dfa.Pool.AVG_INCLUDE_PADDING, True), (hip.dfa.Pool.AVG_EXCLUDE_PADDING, False)):
+                op = hip.dfa.Pool(shape[0], shape[3], shape[1], shape[2], o[0], o[1], k, s, p, np_dt, algo=algo)
+                dst.view(torch.uint8).fill_(0xCD)
+                op.submit(src, dst)
+                torch.cuda.synchronize()
+                hip.assert_bit_equal(dst.cpu().numpy(), oracle.avgpool(x, k, s, p, o, inc),
+                                     "avgpool %s %s include_padding=%s" % (shape, np_dt, inc))
+                op.close()
         for shape, n in (((2, 5, 7, 24), 3), ((1, 1, 1, 1), 2), ((3, 9, 4, 17), 8), ((4, 56, 56, 64), 2)):
             xs = [pool_input(shape, np_dt, seed=20 + i) for i in range(n)]
             for relu in (False, True):

@@ -187,6 +187,19 @@ def test_maxpool_oracle_vs_independent(oracle, case, np_dt):
     assert np.array_equal(oracle.maxpool(x, k, s, p, o), refmath.maxpool(x, k, s, p, o))
 
 
+@pytest.mark.parametrize("include_padding", [True, False])
+@pytest.mark.parametrize("np_dt", [np.uint8, np.int8, np.int32, np.float32])
+@pytest.mark.parametrize("case", [c for c in POOL_CASES if c[0][1] <= 100], ids=lambda c: "x".join(map(str, c[0])))
+def test_avgpool_oracle_vs_independent(oracle, case, np_dt, include_padding):
+    """the reference test's pooling_avg_include_padding / _exclude_padding flags (test_conv_relu_pooling.cc:189-193;
+    one instance: the 7x7 global average behind ResNet's last block, :334-335).  Parity unpinned."""
+    shape, k, s, p, o = case
+    x = pool_input(shape, np_dt, seed=7)
+    a = oracle.avgpool(x, k, s, p, o, include_padding)
+    b = refmath.avgpool(x, k, s, p, o, include_padding)
+    assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
 def test_maxpool_oracle_rejects_window_in_padding(oracle):
     with pytest.raises(RuntimeError):
         oracle.maxpool(np.zeros((1, 4, 4, 16), np.uint8), (2, 2), (2, 2), (0, 0), (4, 4))
