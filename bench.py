@@ -67,12 +67,15 @@ def workloads():
                  "VGG conv3-style unfused conv: N=64 56x56 256->256 u8xs8"),
         "vgg5": (C.ConvCase("vgg5", 64, 512, 14, 14, 512, 0, dst_dt=C.U8),
                  "VGG conv5-style unfused conv: N=64 14x14 512->512 u8xs8"),
+        "vggpool": (C.ConvCase("vggpool", 64, 64, 224, 224, 64, 0, dst_dt=C.U8),
+                    "VGG conv1_2-style unfused conv: N=64 224x224 64->64 u8xs8 (with --fuse-pool: + relu + 2x2/2 max pool, "
+                    "the reference's roadmap op, test_conv_relu_pooling.cc:315-316)"),
         "res3s2": (C.ConvCase("res3s2", 128, 128, 56, 56, 128, 512, stride=(2, 2), dst_dt=C.U8),
                    "ResNet-50 res3a-style stride-2 block: N=128 56x56 128->128->512 s2 u8xs8"),
     }
 
 
-def cpu_baseline(case, data, threads, gpu_out, budget_s=12.0):
+def cpu_baseline(case, data, threads, gpu_out, budget_s=12.0, fuse_pool=0):
     """Oracle port timed on the host cores on a bounded sample of the workload.  This leg
     is the only place bench.py touches oracle/: it also uses the sample's oracle output as
     the checker of what the timed GPU path wrote (never as something measured or shipped)."""
@@ -84,12 +87,15 @@ def cpu_baseline(case, data, threads, gpu_out, budget_s=12.0):
     n = min(case.bs, 32 if impl == "avx512" else 4)
     sub = dict(data, src=data["src"][:n])
     c = replace(case, bs=n)
-    ref = hipref.oracle_conv(orc, c, sub, impl)               # warm-up + checker
+    def run_oracle():
+        r = hipref.oracle_conv(orc, c, sub, impl)
+        return orc.maxpool(r, (2, 2), (2, 2), (0, 0), (r.shape[1] // 2, r.shape[2] // 2)) if fuse_pool else r
+    ref = run_oracle()                                        # warm-up + checker
     hipref.assert_bit_equal(gpu_out[:n], ref, "bench output vs oracle")
     t0 = time.perf_counter()
     reps = 0
     while True:
-        hipref.oracle_conv(orc, c, sub, impl)
+        run_oracle()
         reps += 1
         el = time.perf_counter() - t0
         if el > budget_s or reps >= 100:
@@ -181,6 +187,8 @@ def main():
     ap.add_argument("--workload", default="res2a")
     ap.add_argument("--dst", default=None, help="override dst dtype: u8|s8|s32|f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fuse-pool", action="store_true",
+                    help="unfused conv workloads: 2x2/2 max pooling fused into the conv kernel (conv+relu+pool roadmap op)")
     ap.add_argument("--device-ramp-ms", type=float, default=150.0,
                     help="untimed set-up launches for this long before the warm-up steps (GPU clock ramp); 0 = off")
     ap.add_argument("--launch-stats", type=int, default=0,
@@ -253,7 +261,7 @@ def main():
     case = replace(case, seed=1234 + rank)
     data = C.generate(case)
 
-    op = hipref.make_conv(case, data, force_variant=args.variant)
+    op = hipref.make_conv(case, data, force_variant=args.variant, fuse_pool=2 if args.fuse_pool else 0)
     info = op.info()
     tdt = {C.F32: torch.float32, C.S32: torch.int32, C.S8: torch.int8, C.U8: torch.uint8}[case.dst_dt]
     # rotate over a few src/dst pairs so no step is served from the 256 MiB Infinity Cache
@@ -332,7 +340,7 @@ def main():
             "config": {"workload": "%s (%s), %s out" % (args.workload, desc, dst_name),
                        "per_gpu_batch": case.bs, "global_batch": case.bs * world,
                        "parallelism": "batch-sharded x%d, no data-path collective" % world,
-                       "device_ramp_ms": args.device_ramp_ms,
+                       "device_ramp_ms": args.device_ramp_ms, "fuse_pool": bool(args.fuse_pool),
                        "kernel": info.kernel_name.decode(), "grid": info.grid,
                        # two-launch path (3x3 kernel + 1x1 kernel with the intermediate in HBM): not the fused design
                        "split": info.kernel_name.decode().startswith("split:"),
@@ -356,11 +364,12 @@ def main():
         out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             gpu_head = dsts[0][:32].cpu().numpy()
-            out["cpu_baseline"] = cpu_baseline(case, data, args.cpu_threads or min(os.cpu_count() or 1, 16), gpu_head)
+            out["cpu_baseline"] = cpu_baseline(case, data, args.cpu_threads or min(os.cpu_count() or 1, 16), gpu_head,
+                                               fuse_pool=args.fuse_pool)
             # second leg: one full socket's physical cores (or as many as this box lets the process use)
             sock, usable = socket_cores()
             n_sock = max(1, min(sock, usable))
-            leg = cpu_baseline(case, data, n_sock, gpu_head, budget_s=8.0)
+            leg = cpu_baseline(case, data, n_sock, gpu_head, budget_s=8.0, fuse_pool=args.fuse_pool)
             out["cpu_baseline"]["socket"] = {"value": leg["value"], "unit": leg["unit"], "cores": leg["cores"],
                                              "socket_physical_cores": sock, "usable_cpus": usable,
                                              "sample": leg["sample"]}
