@@ -609,11 +609,7 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
   // while the compute waves copy the weights: all four slots are full when the claim loop starts.
   // (Staged after the barrier it was published ~17 k cycles into the loop -- the loader's first pass
   // through its code is slow -- and half the compute waves sat idle that long: profiles/stamps.py timeline.)
-#ifdef DFX_EXP_NO_COOP1
-  const bool coop1 = false;
-#else
   const bool coop1 = g.static_rounds >= 2;
-#endif
 
   // LDS control words are read and written by WHOLE waves (every lane the same word, the same
   // value) and every loaded value goes through readfirstlane, so that all control flow below is
@@ -1351,13 +1347,8 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
               p0 = tile_dst + ((unsigned)min(pl + h4c, nv1) * rb + ch_off);
               p1 = tile_dst + ((unsigned)min(pl + 1 + h4c, nv1) * rb + ch_off);
             } else {
-#ifdef DFX_EXP_VADDR
-              p0 = tile_dst + ((unsigned)pl * rb + lane_off);
-              p1 = tile_dst + ((unsigned)(pl + 1) * rb + lane_off);
-#else
               p0 = (tile_dst + (size_t)((unsigned)pl * rb)) + (size_t)lane_off;
               p1 = (tile_dst + (size_t)((unsigned)(pl + 1) * rb)) + (size_t)lane_off;
-#endif
             }
             emit_pair<DST, G, decltype(mode_tag)::value>(p0, p1, acc1, e, ia, fb, fc, relu1, a.rm1, w0, w1);
           }
