@@ -75,7 +75,7 @@ def workloads():
     }
 
 
-def cpu_baseline(case, data, threads, gpu_out, budget_s=12.0, fuse_pool=0):
+def cpu_baseline(case, data, threads, gpu_out, budget_s=12.0, fuse_pool=0, max_images=32):
     """Oracle port timed on the host cores on a bounded sample of the workload.  This leg
     is the only place bench.py touches oracle/: it also uses the sample's oracle output as
     the checker of what the timed GPU path wrote (never as something measured or shipped)."""
@@ -84,7 +84,7 @@ def cpu_baseline(case, data, threads, gpu_out, budget_s=12.0, fuse_pool=0):
     import hipref
     orc.set_num_threads(threads)
     impl = "avx512" if orc.have_avx512_vnni() else "scalar_mt"
-    n = min(case.bs, 32 if impl == "avx512" else 4)
+    n = min(case.bs, max_images if impl == "avx512" else 4, len(gpu_out))
     sub = dict(data, src=data["src"][:n])
     c = replace(case, bs=n)
     def run_oracle():
@@ -363,13 +363,14 @@ def main():
         }
         out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
-            gpu_head = dsts[0][:32].cpu().numpy()
+            gpu_head = dsts[0][:128].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(case, data, args.cpu_threads or min(os.cpu_count() or 1, 16), gpu_head,
                                                fuse_pool=args.fuse_pool)
             # second leg: one full socket's physical cores (or as many as this box lets the process use)
             sock, usable = socket_cores()
             n_sock = max(1, min(sock, usable))
-            leg = cpu_baseline(case, data, n_sock, gpu_head, budget_s=8.0, fuse_pool=args.fuse_pool)
+            leg = cpu_baseline(case, data, n_sock, gpu_head, budget_s=8.0, fuse_pool=args.fuse_pool,
+                               max_images=128)  # (a larger sample: 32 images do not feed a socket's threads)
             out["cpu_baseline"]["socket"] = {"value": leg["value"], "unit": leg["unit"], "cores": leg["cores"],
                                              "socket_physical_cores": sock, "usable_cpus": usable,
                                              "sample": leg["sample"]}
