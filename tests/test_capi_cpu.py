@@ -58,3 +58,33 @@ def test_no_cpu_fallback():
     assert "no HIP device" in str(e.value)
     with pytest.raises(dfa.DfxError):
         dfa.Concat(1, 2, 2, [16, 16], np.uint8)
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """ABI drift guard: the descriptor structs of include/dfx.h, compiled by gcc, have the sizes and field
+    offsets the ctypes mirrors in capi.py assume (a field added on one side only would make the library read
+    garbage behind the caller's struct)."""
+    import os
+    import subprocess
+    capi = importlib.import_module("deep-fusion_amd.capi")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pairs = {"dfx_conv_desc": capi.ConvDesc, "dfx_conv_info": capi.ConvInfo, "dfx_concat_desc": capi.ConcatDesc,
+             "dfx_pool_desc": capi.PoolDesc, "dfx_eltwise_desc": capi.EltwiseDesc}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "dfx.h"', 'int main(void) {']
+    for cname, ct in pairs.items():
+        lines.append('printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in ct._fields_:
+            lines.append('printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines.append("return 0; }")
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    seen = {}
+    for ln in subprocess.check_output([str(exe)]).decode().splitlines():
+        a, b, c = ln.split()
+        seen[(a, b)] = int(c)
+    for cname, ct in pairs.items():
+        assert seen[(cname, "size")] == ctypes.sizeof(ct), cname
+        for fname, _ in ct._fields_:
+            assert seen[(cname, fname)] == getattr(ct, fname).offset, (cname, fname)
