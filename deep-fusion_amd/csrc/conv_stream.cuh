@@ -13,10 +13,9 @@
 //    fragments per MFMA against 128 B/clk/CU), at the price of twice the intermediate.
 //  * K is walked in STEPS of two 32-deep MFMA k-blocks.  The packed weight fragments
 //    of a step (2 x OCC or 2 x G KB, laid out by the host in exactly the order the
-//    kernel walks them) travel global -> registers -> LDS, double buffered: the loads
-//    of step t+1 are issued before the MFMAs of step t and written to the other
-//    of step t+3 are issued during step t and written during step t+1 into the third of
-//    three LDS buffers, so that step t+2's weights are already visible (one workgroup
+//    kernel walks them) travel global -> registers -> LDS through THREE LDS buffers: the
+//    loads of step t+3 are issued during step t and written during step t+1 into the
+//    buffer step t freed, so that step t+2's weights are already visible (one workgroup
 //    barrier per step) when a wave prefetches them.  The four waves share every weight
 //    fragment, so L2 sees each weight byte once per 128 pixels.  The next input chunk /
 //    next unit's tile is likewise fetched into registers during the last step before

@@ -152,11 +152,22 @@ struct dfx_conv {
   void *d_mid;
   hipEvent_t split_done;   // split ops: recorded behind the second launch; the next submit's first launch waits
   hipStream_t split_last;  // for it when it runs on another stream (the two launches share d_mid)
+  bool split_recorded;     // a previous submit exists (split_last may legitimately be the NULL stream)
   std::mutex *split_mu;    // split ops: orders concurrent submits from several host threads
   int icb, ocb, G, grid, block, lds;
   void *d_wei, *d_wei1, *d_consts;
   int *d_queue;  // MFMA variant: ring of DFX_QUEUE_RING x {next unit, finished loaders}, one slot per launch in flight
   unsigned launch_seq;
+  // In-flight guard of the queue ring.  Launches on ONE stream are ordered by the stream; as soon as a handle
+  // has been submitted on a second stream every launch records its slot's event, and a launch that finds its
+  // slot last used on another stream first waits (on the device) for that launch: a 17th concurrent launch
+  // queues up behind the 1st instead of sharing its queue words.
+  std::mutex *ring_mu;
+  hipEvent_t slot_ev[DFX_QUEUE_RING];
+  hipStream_t slot_stream[DFX_QUEUE_RING];
+  unsigned char slot_state[DFX_QUEUE_RING];  // 0 never used, 1 used (no event recorded), 2 used + event recorded
+  bool multi_stream;
+  hipStream_t first_stream;
   int *trace_host;  // DFX_TRACE builds only
   unsigned long long *d_prof;  // DFX_STAMPS builds only
   bool weights_set;
@@ -246,11 +257,17 @@ int dfx_stream_sync(dfx_stream_t s) {
 }
 int dfx_stream_wait_stream(dfx_stream_t waiter, dfx_stream_t producer) {
   if (waiter == producer) return DFX_OK;
-  hipEvent_t e;
-  HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  hipError_t r = hipEventRecord(e, (hipStream_t)producer);
+  // the event must live on the PRODUCER stream's device (the streams of a multi-device pipeline differ)
+  int cur = -1, pdev = -1;
+  (void)hipGetDevice(&cur);
+  if (producer && hipStreamGetDevice((hipStream_t)producer, &pdev) != hipSuccess) pdev = -1;
+  if (pdev >= 0 && pdev != cur) (void)hipSetDevice(pdev);
+  hipEvent_t e = nullptr;
+  hipError_t r = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  if (r == hipSuccess) r = hipEventRecord(e, (hipStream_t)producer);
+  if (pdev >= 0 && pdev != cur) (void)hipSetDevice(cur);
   if (r == hipSuccess) r = hipStreamWaitEvent((hipStream_t)waiter, e, 0);
-  (void)hipEventDestroy(e);  // (released once the recorded work has completed)
+  if (e) (void)hipEventDestroy(e);  // (released once the recorded work has completed)
   HIP_TRY(r);
   return DFX_OK;
 }
@@ -631,6 +648,9 @@ static void conv_release(dfx_conv *h) {
   (void)hipFree(h->d_mid);
   if (h->split_done) (void)hipEventDestroy(h->split_done);
   delete h->split_mu;
+  for (unsigned i = 0; i < DFX_QUEUE_RING; ++i)
+    if (h->slot_ev[i]) (void)hipEventDestroy(h->slot_ev[i]);
+  delete h->ring_mu;
   conv_release(h->split0);
   conv_release(h->split1);
   delete h;
@@ -863,6 +883,11 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
       return fail(DFX_ERR_HIP, "conv_create: cannot allocate the unit queue");
     }
     h->geom.queue = h->d_queue;
+    h->ring_mu = new (std::nothrow) std::mutex();
+    if (!h->ring_mu) {
+      conv_release(h);
+      return fail(DFX_ERR_HIP, "out of host memory");
+    }
     h->geom.mode0 = h->geom.mode1 = 0;
     {
       const int teams = h->grid * MFMA_TEAMS;
@@ -1356,12 +1381,13 @@ int dfx_conv_submit(dfx_conv_t *h, const void *src_dev, void *dst_dev, dfx_strea
     // other, whatever streams they come on -- the first launch of a submit waits (on the device) for
     // the second launch of the previous one.  Other work on those streams is not held up.
     std::lock_guard<std::mutex> lk(*h->split_mu);
-    if (h->split_last && h->split_last != (hipStream_t)s) HIP_TRY(hipStreamWaitEvent((hipStream_t)s, h->split_done, 0));
+    if (h->split_recorded && h->split_last != (hipStream_t)s) HIP_TRY(hipStreamWaitEvent((hipStream_t)s, h->split_done, 0));
     int rc0 = dfx_conv_submit(h->split0, src_dev, h->d_mid, s);
     if (rc0 == DFX_OK) rc0 = dfx_conv_submit(h->split1, h->d_mid, dst_dev, s);
     if (rc0 != DFX_OK) return rc0;
     HIP_TRY(hipEventRecord(h->split_done, (hipStream_t)s));
     h->split_last = (hipStream_t)s;
+    h->split_recorded = true;
     return DFX_OK;
   }
   // per-launch copies: concurrent submits of one handle (other host threads, other streams) share
@@ -1370,7 +1396,38 @@ int dfx_conv_submit(dfx_conv_t *h, const void *src_dev, void *dst_dev, dfx_strea
   a.src = (const uint8_t *)src_dev;
   a.dst = dst_dev;
   MfmaGeom g = h->geom;
-  if (g.queue) g.queue += 2 * (__atomic_fetch_add(&h->launch_seq, 1u, __ATOMIC_RELAXED) % DFX_QUEUE_RING);
+  if (g.queue) {
+    // one queue-ring slot per launch in flight; see struct dfx_conv for the guard
+    const hipStream_t st = (hipStream_t)s;
+    std::lock_guard<std::mutex> lk(*h->ring_mu);
+    const unsigned slot = h->launch_seq++ % DFX_QUEUE_RING;
+    if (h->launch_seq == 1) h->first_stream = st;
+    if (!h->multi_stream && st != h->first_stream) {
+      // second stream seen: the launches so far (all on first_stream, no events) are covered by ONE event
+      // recorded there now -- a stream event stands for everything submitted before it
+      h->multi_stream = true;
+      hipEvent_t e0 = nullptr;
+      HIP_TRY(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+      hipError_t r = hipEventRecord(e0, h->first_stream);
+      if (r == hipSuccess) r = hipStreamWaitEvent(st, e0, 0);
+      (void)hipEventDestroy(e0);
+      if (r != hipSuccess) HIP_TRY(hipDeviceSynchronize());  // (first_stream already destroyed by the caller)
+      for (unsigned i = 0; i < DFX_QUEUE_RING; ++i)
+        if (h->slot_state[i] == 1) h->slot_state[i] = 0;  // their launches are ordered before this one now
+    }
+    if (h->slot_state[slot] == 2 && h->slot_stream[slot] != st) HIP_TRY(hipStreamWaitEvent(st, h->slot_ev[slot], 0));
+    g.queue += 2 * slot;
+    if (mfma_dispatch(h, a, g, st, 0) != 0) return fail(DFX_ERR_UNSUPPORTED, "conv_submit: no kernel instance for this op");
+    HIP_TRY(hipGetLastError());
+    h->slot_stream[slot] = st;
+    h->slot_state[slot] = 1;
+    if (h->multi_stream) {
+      if (!h->slot_ev[slot]) HIP_TRY(hipEventCreateWithFlags(&h->slot_ev[slot], hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(h->slot_ev[slot], st));
+      h->slot_state[slot] = 2;
+    }
+    return DFX_OK;
+  }
   int rc;
   if (h->variant != DFX_VARIANT_GENERIC)
     rc = mfma_dispatch(h, a, g, (hipStream_t)s, 0);
@@ -1624,6 +1681,11 @@ int dfx_pool_submit(dfx_pool_t *h, const void *src_dev, void *dst_dev, dfx_strea
   PoolArgs a = h->args;  // per-launch copy: concurrent submits on several streams are independent
   a.src = (const unsigned char *)src_dev;
   a.dst = (unsigned char *)dst_dev;
+  if (a.vec && (((uintptr_t)src_dev | (uintptr_t)dst_dev) % 16)) {  // 16-byte vector path needs aligned buffers:
+    a.vec = 0;                                                       // misaligned ones take the per-channel path
+    a.groups = a.c;
+    a.total = (long long)a.bs * a.oh * a.ow * a.groups;
+  }
   if (launch_pool(a, (hipStream_t)s) != 0) return fail(DFX_ERR_INVALID, "pool_submit: bad dtype");
   HIP_TRY(hipGetLastError());
   return DFX_OK;

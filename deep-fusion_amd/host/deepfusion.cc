@@ -71,7 +71,10 @@ struct memory_state {
   size_t bytes = 0;
   unsigned long long host_version = 1;      // bumped by every data() call
   unsigned long long uploaded_version = 0;  // host_version the device copy reflects
-  dfx_stream_t producer = nullptr;          // stream of the op that last wrote the device copy asynchronously
+  dfx_stream_t producer = nullptr;          // stream of the op whose launch, possibly still in flight, last wrote the
+                                            // device copy; cleared once that stream has been synchronised
+  bool device_ahead = false;                // the device copy is NEWER than the host bytes (written by an op and
+                                            // not downloaded yet): an upload would destroy it
 };
 
 // FNV-1a over 8-byte words (+ tail): the trigger for re-packing borrowed weight tensors.  The
@@ -146,16 +149,20 @@ struct op_state {
   // Make the device copy of input `m` current; returns the device pointer.
   // always == true is the reference-compatible submit(): the caller may have refilled the host
   // buffer through a pointer it fetched once (the reference reads host memory on every submit),
-  // so the (pinned) host bytes are uploaded every time.  The asynchronous extension path
+  // so the (pinned) host bytes are uploaded every time -- unless the device copy is the NEWER one
+  // (an op wrote it with submit_async() and nobody has called data() since: the host bytes are
+  // stale, uploading them would overwrite the producer's result).  The asynchronous extension path
   // (submit_async / upload / device_data) skips the copy while no data() call has bumped the
   // version, and orders itself behind the op that produced the device copy on another stream.
   void *sync_in(memory &m, bool always) {
     memory_state *s = m.st_;
     if (!s->device) check_dfx(dfx_mem_alloc_device(&s->device, s->bytes), "device alloc");
     if (s->producer && s->producer != stream) check_dfx(dfx_stream_wait_stream(stream, s->producer), "stream wait");
-    if (always || s->uploaded_version != s->host_version) {
+    const bool host_touched = s->uploaded_version != s->host_version;
+    if (host_touched || (always && !s->device_ahead)) {
       check_dfx(dfx_memcpy_h2d(s->device, s->host, s->bytes, stream), "H2D copy");
       s->uploaded_version = s->host_version;
+      s->device_ahead = false;
     }
     return s->device;
   }
@@ -164,7 +171,21 @@ struct op_state {
     if (!s->device) check_dfx(dfx_mem_alloc_device(&s->device, s->bytes), "device alloc");
     s->producer = stream;
     s->uploaded_version = s->host_version;  // the device copy is about to become the newer one
+    s->device_ahead = true;
     return s->device;
+  }
+  // this op's stream has just been synchronised: nothing it launched is still writing m, consumers on
+  // other streams need not (and, once this op is gone, could not) wait on it
+  void settled(memory &m) {
+    if (m.st_->producer == stream) m.st_->producer = nullptr;
+  }
+  // the op is being destroyed while a launch of it may still be writing m (the reference only asks that
+  // tensors outlive ops): finish that work, then forget the stream -- it is about to be destroyed
+  void retire(memory &m) {
+    if (stream && m.st_->producer == stream) {
+      dfx_stream_sync(stream);
+      m.st_->producer = nullptr;
+    }
   }
   // device-side duration of what infer() enqueued, printed like the reference's profiling wrapper
   dfx_event_t ev0 = nullptr, ev1 = nullptr;
@@ -188,9 +209,14 @@ struct op_state {
     memory_state *s = m.st_;
     check_dfx(dfx_memcpy_d2h(s->host, s->device, s->bytes, stream), "D2H copy");
     s->uploaded_version = s->host_version;  // host == device after the copy
+    s->device_ahead = false;
   }
   // sharded submit wrote m's HOST buffer directly: any device copy is stale
-  static void host_is_current(memory &m) { m.st_->uploaded_version = 0; m.st_->producer = nullptr; }
+  static void host_is_current(memory &m) {
+    m.st_->uploaded_version = 0;
+    m.st_->producer = nullptr;
+    m.st_->device_ahead = false;
+  }
   ~op_state() {
     if (ev0) dfx_event_destroy(ev0);
     if (ev1) dfx_event_destroy(ev1);
@@ -252,11 +278,18 @@ void memory::upload() {
   check_dfx(dfx_memcpy_h2d(device_data(), st_->host, st_->bytes, nullptr), "H2D copy");
   check_dfx(dfx_stream_sync(nullptr), "sync");
   st_->uploaded_version = st_->host_version;
+  st_->device_ahead = false;
 }
 void memory::download() {
+  if (!st_->device) return;  // no device copy exists (e.g. batch-sharded ops work host to host): the host bytes are current
+  if (st_->producer) {  // the op that wrote the device copy may still be running on its own stream
+    check_dfx(dfx_stream_sync(st_->producer), "stream sync");
+    st_->producer = nullptr;
+  }
   check_dfx(dfx_memcpy_d2h(st_->host, device_data(), st_->bytes, nullptr), "D2H copy");
   check_dfx(dfx_stream_sync(nullptr), "sync");
   st_->uploaded_version = st_->host_version;
+  st_->device_ahead = false;
 }
 
 // ---------------------------------------------------------------------------
@@ -279,7 +312,7 @@ public:
           const std::unique_ptr<memory> &bia1x1, bool relu0, bool relu1, round_mode rm0,
           round_mode rm1)
       : src_(src.get()), wei_(wei.get()), bia_(bia.get()), wei1_(wei1x1.get()), bia1_(bia1x1.get()),
-        dst_(dst.get()), scales0_(scales0), scales1_(scales1), h_(nullptr), wei_seen_(0) {
+        dst_(dst.get()), scales0_(scales0), scales1_(scales1), h_(nullptr), packed_hash_(0), packed_versions_(0) {
     using fmt = memory::format;
     if (!src_ || !wei_ || !dst_) error_and_exit("Init Conv op failed! (null tensor)");
     // dtype / format gate of jit_conv_kernel::init_conf (jit_conv_kernel.cc:531-564)
@@ -353,6 +386,7 @@ public:
       dfx_mem_free_device(sh.dst);
     }
     if (!shards_.empty()) dfx_set_device(shards_[0].r.device);
+    st_.retire(*dst_);
     dfx_conv_destroy(h_);
   }
 
@@ -365,6 +399,7 @@ public:
     run(true);
     st_.fetch_out(*dst_);
     check_dfx(dfx_stream_sync(st_.stream), "stream sync");
+    st_.settled(*dst_);
   }
   // (sharded: host in -> host out like submit(), without the final wait; the device-resident
   // chaining extension is single-device)
@@ -373,8 +408,12 @@ public:
     else run(false);
   }
   void wait() override {
-    if (!shards_.empty()) sync_shards();
-    else check_dfx(dfx_stream_sync(st_.stream), "stream sync");
+    if (!shards_.empty()) {
+      sync_shards();
+    } else {
+      check_dfx(dfx_stream_sync(st_.stream), "stream sync");
+      st_.settled(*dst_);
+    }
   }
 
 protected:
@@ -388,7 +427,11 @@ protected:
     if (bia_) v = hash_bytes(bia_->host_data(), bia_->buffer_size(), v);
     if (wei1_) v = hash_bytes(wei1_->host_data(), wei1_->buffer_size(), v);
     if (bia1_) v = hash_bytes(bia1_->host_data(), bia1_->buffer_size(), v);
-    return v | 1ull << 63;  // (never equal to a version sum)
+    return v | 1ull;  // (never 0 = "nothing packed yet")
+  }
+  unsigned long long weights_versions() const {
+    return wei_->host_version() + (bia_ ? bia_->host_version() : 0) + (wei1_ ? wei1_->host_version() : 0) +
+           (bia1_ ? bia1_->host_version() : 0);
   }
   // every shard: upload its images from the host tensor, launch, download into the host tensor
   void enqueue_shards() {
@@ -424,23 +467,22 @@ protected:
   // which trusts the data() version counters.
   void run(bool sync_host) {
     // weights are borrowed host tensors the caller may rewrite between submits (the reference
-    // re-reads them on every call)
-    unsigned long long v;
-    if (sync_host) {
-      v = weights_hash();
-    } else {
-      v = wei_->host_version() + (bia_ ? bia_->host_version() : 0) +
-          (wei1_ ? wei1_->host_version() : 0) + (bia1_ ? bia1_->host_version() : 0);
-      if (wei_seen_ >> 63) v = wei_seen_;  // packed from these very bytes by a synchronous submit
-    }
-    if (v != wei_seen_) {
-      check_dfx(dfx_stream_sync(st_.stream), "stream sync");  // no launch may still read the old copy
-      check_dfx(dfx_conv_set_weights(h_, (const int8_t *)wei_->host_data(),
-                                     bia_ ? bia_->host_data() : nullptr, scales0_.data(),
-                                     wei1_ ? (const int8_t *)wei1_->host_data() : nullptr,
-                                     bia1_ ? bia1_->host_data() : nullptr, scales1_.data()),
-                "conv set_weights");
-      wei_seen_ = v;
+    // re-reads them on every call).  What the handle holds is described by TWO values taken at pack
+    // time: the hash of the packed bytes and the sum of the tensors' data() counters.  submit() re-reads
+    // the bytes (hash); submit_async() trusts the counters, and only when they moved looks at the bytes.
+    const unsigned long long vers = weights_versions();
+    if (sync_host || vers != packed_versions_) {
+      const unsigned long long hash = weights_hash();
+      if (hash != packed_hash_) {
+        check_dfx(dfx_stream_sync(st_.stream), "stream sync");  // no launch may still read the old copy
+        check_dfx(dfx_conv_set_weights(h_, (const int8_t *)wei_->host_data(),
+                                       bia_ ? bia_->host_data() : nullptr, scales0_.data(),
+                                       wei1_ ? (const int8_t *)wei1_->host_data() : nullptr,
+                                       bia1_ ? bia1_->host_data() : nullptr, scales1_.data()),
+                  "conv set_weights");
+        packed_hash_ = hash;
+      }
+      packed_versions_ = vers;
     }
     void *s = st_.sync_in(*src_, sync_host);
     void *o = st_.device_out(*dst_);
@@ -462,7 +504,7 @@ private:
   memory *src_, *wei_, *bia_, *wei1_, *bia1_, *dst_;
   std::vector<float> scales0_, scales1_;  // owned copies (the reference keeps a dangling pointer)
   dfx_conv_t *h_;
-  unsigned long long wei_seen_;
+  unsigned long long packed_hash_, packed_versions_;  // what h_ was packed from (see run())
   detail::op_state st_;
   std::vector<shard> shards_;  // DEEPFUSION_DEVICES > 1: one entry per batch shard; empty otherwise
 };
@@ -529,6 +571,7 @@ public:
       dfx_mem_free_device(sh.dst);
     }
     if (!shards_.empty()) dfx_set_device(shards_[0].r.device);
+    st_.retire(*dst_);
     dfx_concat_destroy(h_);
   }
 
@@ -541,14 +584,19 @@ public:
     run(true);
     st_.fetch_out(*dst_);
     check_dfx(dfx_stream_sync(st_.stream), "stream sync");
+    st_.settled(*dst_);
   }
   void submit_async() override {
     if (!shards_.empty()) enqueue_shards();
     else run(false);
   }
   void wait() override {
-    if (!shards_.empty()) sync_shards();
-    else check_dfx(dfx_stream_sync(st_.stream), "stream sync");
+    if (!shards_.empty()) {
+      sync_shards();
+    } else {
+      check_dfx(dfx_stream_sync(st_.stream), "stream sync");
+      st_.settled(*dst_);
+    }
   }
 
 protected:
@@ -616,7 +664,7 @@ public:
                std::array<int, 2> pk, std::array<int, 2> ps, std::array<int, 2> pp, std::unique_ptr<memory> &dst,
                bool relu, const std::vector<float> &scales, round_mode rm, pool_algo algo)
       : src_(src.get()), wei_(wei.get()), bia_(bia.get()), dst_(dst.get()), scales_(scales), conv_(nullptr),
-        pool_(nullptr), mid_(nullptr), wei_seen_(0) {
+        pool_(nullptr), mid_(nullptr), packed_hash_(0), packed_versions_(0) {
     using fmt = memory::format;
     if (!src_ || !wei_ || !dst_) error_and_exit("Init ConvReluPool op failed! (null tensor)");
     bool ok = src_->data_type() == memory::dtype::u8 && wei_->data_type() == memory::dtype::s8 &&
@@ -672,6 +720,7 @@ public:
     st_.ensure_stream();
   }
   ~op_conv_pool() override {
+    st_.retire(*dst_);
     dfx_conv_destroy(conv_);
     if (pool_) dfx_pool_destroy(pool_);
     if (mid_) dfx_mem_free_device(mid_);
@@ -680,28 +729,30 @@ public:
     run(true);
     st_.fetch_out(*dst_);
     check_dfx(dfx_stream_sync(st_.stream), "stream sync");
+    st_.settled(*dst_);
   }
   void submit_async() override { run(false); }
-  void wait() override { check_dfx(dfx_stream_sync(st_.stream), "stream sync"); }
+  void wait() override {
+    check_dfx(dfx_stream_sync(st_.stream), "stream sync");
+    st_.settled(*dst_);
+  }
 
 protected:
   void infer() override { run(true); }
   void run(bool sync_host) {
-    unsigned long long v;
-    if (sync_host) {
-      v = detail::hash_bytes(wei_->host_data(), wei_->buffer_size(), 1469598103934665603ull);
-      if (bia_) v = detail::hash_bytes(bia_->host_data(), bia_->buffer_size(), v);
-      v |= 1ull << 63;
-    } else {
-      v = wei_->host_version() + (bia_ ? bia_->host_version() : 0);
-      if (wei_seen_ >> 63) v = wei_seen_;
-    }
-    if (v != wei_seen_) {
-      check_dfx(dfx_stream_sync(st_.stream), "stream sync");
-      check_dfx(dfx_conv_set_weights(conv_, (const int8_t *)wei_->host_data(), bia_ ? bia_->host_data() : nullptr,
-                                     scales_.data(), nullptr, nullptr, nullptr),
-                "conv set_weights");
-      wei_seen_ = v;
+    const unsigned long long vers = wei_->host_version() + (bia_ ? bia_->host_version() : 0);
+    if (sync_host || vers != packed_versions_) {  // (as op_conv::run)
+      unsigned long long hash = detail::hash_bytes(wei_->host_data(), wei_->buffer_size(), 1469598103934665603ull);
+      if (bia_) hash = detail::hash_bytes(bia_->host_data(), bia_->buffer_size(), hash);
+      hash |= 1ull;
+      if (hash != packed_hash_) {
+        check_dfx(dfx_stream_sync(st_.stream), "stream sync");
+        check_dfx(dfx_conv_set_weights(conv_, (const int8_t *)wei_->host_data(), bia_ ? bia_->host_data() : nullptr,
+                                       scales_.data(), nullptr, nullptr, nullptr),
+                  "conv set_weights");
+        packed_hash_ = hash;
+      }
+      packed_versions_ = vers;
     }
     void *s = st_.sync_in(*src_, sync_host);
     void *o = st_.device_out(*dst_);
@@ -722,7 +773,7 @@ private:
   dfx_conv_t *conv_;
   dfx_pool_t *pool_;
   void *mid_;
-  unsigned long long wei_seen_;
+  unsigned long long packed_hash_, packed_versions_;
   detail::op_state st_;
 };
 
@@ -746,14 +797,21 @@ public:
     if (dfx_eltwise_create(&d, &h_) != DFX_OK) error_and_exit("Init EltwiseSum op failed! (%s)", dfx_last_error());
     st_.ensure_stream();
   }
-  ~op_eltwise() override { dfx_eltwise_destroy(h_); }
+  ~op_eltwise() override {
+    st_.retire(*dst_);
+    dfx_eltwise_destroy(h_);
+  }
   void submit() override {
     run(true);
     st_.fetch_out(*dst_);
     check_dfx(dfx_stream_sync(st_.stream), "stream sync");
+    st_.settled(*dst_);
   }
   void submit_async() override { run(false); }
-  void wait() override { check_dfx(dfx_stream_sync(st_.stream), "stream sync"); }
+  void wait() override {
+    check_dfx(dfx_stream_sync(st_.stream), "stream sync");
+    st_.settled(*dst_);
+  }
 
 protected:
   void infer() override { run(true); }

@@ -4,6 +4,7 @@
 // raw files; tests/test_dropin.py re-checks them against the CPU oracle.
 //   dropin_check <outdir>
 #include <cstdio>
+#include <cstring>
 #include <string>
 
 #include "cli_flags.h"
@@ -61,6 +62,62 @@ int main(int argc, char **argv) {
     c->submit();
     dump(out + "/fused_src3.bin", src->host_data(), src->buffer_size());
     dump(out + "/fused_dst3.bin", dst->host_data(), dst->buffer_size());
+  }
+  // ---- coherence rules of the asynchronous extension, and op lifetime (two chained unfused convs
+  //      a: src -> mid, b: mid -> dst; N=2, 9x9, 32 -> 32 -> 32, u8) ----
+  {
+    const int bs = 2, ic = 32, ih = 9, iw = 9, oc = 32;
+    auto mk_act = [&]() {
+      return std::unique_ptr<memory>(new memory(memory::nchw_dims{bs, ic, ih, iw}, memory::format::nhwc, memory::dtype::u8));
+    };
+    auto mk_wei = [&]() {
+      return std::unique_ptr<memory>(new memory(memory::nchw_dims{oc, ic, 3, 3}, memory::format::OIhw4i16o4i, memory::dtype::s8));
+    };
+    std::unique_ptr<memory> src = mk_act(), mid = mk_act(), dst = mk_act(), wa = mk_wei(), wb = mk_wei();
+    static const std::unique_ptr<memory> none;
+    uint8_t *s = (uint8_t *)src->data();
+    for (size_t i = 0; i < src->size(); ++i) s[i] = (uint8_t)(g.next() % 17);
+    std::vector<s8> wa0(wa->size()), wa1(wa->size()), wb0(wb->size());
+    for (auto &v : wa0) v = (s8)((int)(g.next() % 21) - 10);
+    for (auto &v : wa1) v = (s8)((int)(g.next() % 21) - 10);
+    for (auto &v : wb0) v = (s8)((int)(g.next() % 21) - 10);
+    reorder_weights(wa0.data(), wa);
+    reorder_weights(wb0.data(), wb);
+    auto a = conv(src, wa, none, {1, 1}, {1, 1}, mid, true, {1.f / 32}, round_mode::nearest);
+    auto b = conv(mid, wb, none, {1, 1}, {1, 1}, dst, true, {1.f / 32}, round_mode::nearest);
+    dump(out + "/chain_src.bin", src->host_data(), src->buffer_size());
+    dump(out + "/chain_wa0_oihw.bin", wa0.data(), wa0.size());
+    dump(out + "/chain_wa1_oihw.bin", wa1.data(), wa1.size());
+    dump(out + "/chain_wb_oihw.bin", wb0.data(), wb0.size());
+    // Device-resident chaining is the single-device extension; with DEEPFUSION_DEVICES (batch shards, host in ->
+    // host out) the same files are produced through synchronous submits.
+    const char *dv = getenv("DEEPFUSION_DEVICES");
+    const bool sharded = dv && *dv && strcmp(dv, "1") != 0;
+    // (1) a synchronous submit packs the weights; the caller then rewrites them through data() and goes on
+    //     with submit_async(): the new weights must be used
+    a->submit();
+    dump(out + "/chain_mid0.bin", mid->host_data(), mid->buffer_size());
+    reorder_weights(wa1.data(), wa);  // (writes through wa->data())
+    a->submit_async();
+    a->wait();
+    mid->download();  // (sharded: the shards wrote the host buffer themselves; nothing to fetch)
+    dump(out + "/chain_mid1.bin", mid->host_data(), mid->buffer_size());
+    // (2) producer asynchronous, consumer synchronous: mid's device copy (weights wa0) is the newer side,
+    //     its host bytes are overwritten with garbage that must NOT reach the device
+    reorder_weights(wa0.data(), wa);
+    if (!sharded) {
+      a->submit_async();  // device mid = conv(src, wa0); host mid still holds the wa1 result
+      memset(const_cast<void *>(mid->host_data()), 0xEE, mid->buffer_size());
+    } else {
+      a->submit();
+    }
+    b->submit();
+    dump(out + "/chain_dst_a0.bin", dst->host_data(), dst->buffer_size());
+    // (3) the producing op is destroyed before the consumer runs (tensors outlive ops; ops may go)
+    if (!sharded) a->submit_async(); else a->submit();
+    a.reset();
+    b->submit();
+    dump(out + "/chain_dst_gone.bin", dst->host_data(), dst->buffer_size());
   }
   // ---- fused conv, N=5 (uneven over 2 or 3 batch shards: DEEPFUSION_DEVICES), s32 out ----
   {

@@ -12,15 +12,22 @@
 // Host/device coherence (the reference has one address space; this build has two):
 //   * memory::data() still returns a HOST pointer that callers read and write
 //     directly.  The buffer is pinned host memory.
-//   * Every call of data() marks the tensor "host-dirty" (the caller may write
-//     through the pointer).  submit() uploads host-dirty inputs (and re-packs
-//     host-dirty weights), launches ONE kernel, downloads the destination and
-//     synchronises: after submit() returns, dst->data() holds the result, exactly
-//     like the reference's synchronous OpenMP execution (deepfusion.cc:90-103).
+//   * submit() has the reference's semantics: the caller's host buffers are re-read on EVERY
+//     call.  Inputs are uploaded every time (also when the caller refilled them through a
+//     pointer fetched once, without calling data() again), borrowed weight / bias tensors are
+//     hashed and re-packed when their bytes changed; then ONE kernel is launched, the
+//     destination downloaded and the stream synchronised: after submit() returns,
+//     dst->data() holds the result, exactly like the reference's synchronous OpenMP
+//     execution (deepfusion.cc:90-103).  The one exception: an input whose device copy was
+//     written by another op's submit_async() and that nobody has touched through data()
+//     since is NOT uploaded -- its host bytes are the stale side.
 //   * Extensions for device-resident pipelines (not in the reference):
-//     op::submit_async() skips the download and the synchronisation;
-//     memory::device_data() exposes the device buffer; memory::download() /
-//     op::wait() complete a transfer explicitly.
+//     op::submit_async() skips the download and the synchronisation and trusts the
+//     per-tensor data() counters instead of re-reading host memory (every call of data()
+//     marks the tensor "host-dirty": it is uploaded / its weights are re-packed by the next
+//     submit_async()); memory::device_data() exposes the device buffer; memory::download() /
+//     op::wait() complete a transfer explicitly.  With DEEPFUSION_PROFILE=1 every submit,
+//     submit_async() included, waits for its launch (it prints the launch's duration).
 //
 // Lifetime rule kept from the reference (op_conv.h:81-95, op_concat.h:53-56):
 // an op borrows the tensors it was built from; they must outlive it.

@@ -190,7 +190,9 @@ int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei_blocked, const void *b
 /* asynchronous: enqueues on `s`; src_dev/dst_dev are device pointers that must
  * stay valid until the stream reaches the kernel's end.  A handle may be submitted from several
  * host threads and on several streams at once: every launch works on its own copy of the
- * arguments and its own unit-queue slot (up to 16 launches of one handle in flight).  An op whose
+ * arguments and its own unit-queue slot.  There are 16 slots per handle: launches on one stream are
+ * ordered anyway; with several streams a launch that finds its slot last used on ANOTHER stream first
+ * waits, on the device, for that launch (a 17th concurrent launch queues behind the 1st).  An op whose
  * dfx_conv_info.kernel_name starts with "split:" (two launches through a handle-owned
  * intermediate) may be submitted the same way, but its submits are ordered among each other on the
  * device: the first launch of one waits for the second launch of the previous one. */

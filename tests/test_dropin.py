@@ -45,6 +45,23 @@ def test_dropin_cpp_api(oracle, tmp_path):
     src3 = _load(d, "fused_src3.bin", np.uint8, (2, 13, 13, 32))       # refilled through a cached pointer
     assert np.array_equal(_load(d, "fused_dst3.bin", np.uint8, (2, 13, 13, 64)), ref_fused(src3))
     assert not np.array_equal(src3, src)
+    # coherence of the asynchronous extension + op lifetime: two chained unfused convs
+    csrc = _load(d, "chain_src.bin", np.uint8, (2, 9, 9, 32))
+    wa0, wa1, wbb = (_load(d, "chain_%s_oihw.bin" % n, np.int8, (32, 32, 3, 3)) for n in ("wa0", "wa1", "wb"))
+    sc = np.array([1.0 / 32], dtype=np.float32)
+
+    def ref_plain(x, w):
+        return oracle.conv(x, oracle.reorder_oihw_to_blocked(w), w.shape, (1, 1), (1, 1), C.U8, sc, relu0=True)
+    mid0, mid1 = ref_plain(csrc, wa0), ref_plain(csrc, wa1)
+    assert not np.array_equal(mid0, mid1)
+    assert np.array_equal(_load(d, "chain_mid0.bin", np.uint8, mid0.shape), mid0)
+    assert np.array_equal(_load(d, "chain_mid1.bin", np.uint8, mid1.shape), mid1), \
+        "submit_async() after a synchronous submit ignored weights rewritten through data()"
+    want = ref_plain(mid0, wbb)
+    assert np.array_equal(_load(d, "chain_dst_a0.bin", np.uint8, want.shape), want), \
+        "a synchronous consumer uploaded stale host bytes over an asynchronous producer's device result"
+    assert np.array_equal(_load(d, "chain_dst_gone.bin", np.uint8, want.shape), want), \
+        "consumer after the producing op was destroyed"
     # fused conv N=5, s32 out, no bias
     s5 = _load(d, "n5_src.bin", np.uint8, (5, 9, 11, 32))
     w50 = _load(d, "n5_w0_oihw.bin", np.int8, (32, 32, 3, 3))
@@ -103,6 +120,12 @@ def test_bench_tools_run():
                                    "-kw", "3", "-sh", "1", "-sw", "1", "-ph", "1", "-pw", "1", "-ic", "32", "-oc", "32",
                                    "-oc1x1", "64", "-dtype", "u8", "-burning_iter", "2", "-iter", "3"])
     assert b"DeepFusion Conv avg time" in out
+    # -cold_cache: the reference's cold-cache protocol (CMakeLists.txt:60-61, test/test_utils.cc:23-45)
+    for tool, args in (("bench_concat", ["-n", "1", "-c", "16,16", "-h", "8", "-w", "8", "-dtype", "s8"]),
+                       ("bench_conv", ["-bs", "2", "-ih", "28", "-iw", "28", "-ic", "32", "-oc", "32", "-oc1x1", "64",
+                                       "-dtype", "u8"])):
+        out = subprocess.check_output([os.path.join(TOOLS, tool)] + args + ["-burning_iter", "1", "-iter", "2", "-cold_cache"])
+        assert b"COLD caches" in out and b"warm caches" in out, out
 
 
 def test_init_failure_exits_like_reference(tmp_path):

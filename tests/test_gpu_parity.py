@@ -410,6 +410,71 @@ def test_full_size_config5_rows(hip, oracle):
     hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), "config 5")
 
 
+def test_full_size_config5(hip, oracle):
+    """BASELINE.json configs[4] at FULL size (N=64, 224x224, 64->64->128, f32 out; 1.64 GB of dst, 24 units per
+    loader through the lazy device queue): the HIP path at full size, the oracle on images {0,1,31,32,62,63}
+    (images are independent, op_conv.cc:155-156), and the size-independent batch-shard property on images
+    [20, 24).  f32 compared bit for bit (0 ulp; north_star allows 1)."""
+    import torch
+    case = replace(C.CONFIG5_TINY, name="cfg5", bs=64)
+    rng = np.random.default_rng(case.seed)
+    data = C.generate(replace(case, bs=1))            # weights, bias, scales (seeded; independent of bs)
+    data["src"] = rng.integers(0, 17, (case.bs, case.ih, case.iw, case.ic), dtype=np.uint8)
+    op = hip.make_conv(case, data)
+    info = op.info()
+    assert info.variant == hip.dfa.VARIANT_MFMA_FUSED
+    src = torch.from_numpy(data["src"]).cuda()
+    dst = torch.empty(op.dst_shape, dtype=torch.float32, device="cuda")
+    dst.view(torch.uint8).fill_(0xCD)
+    op.submit(src, dst)
+    torch.cuda.synchronize()
+    op.close()
+    pick = [0, 1, 31, 32, 62, 63]
+    ref = hip.oracle_conv(oracle, replace(case, bs=len(pick)), dict(data, src=np.ascontiguousarray(data["src"][pick])))
+    got = dst[pick].cpu().numpy()
+    hip.assert_bit_equal(got, ref, "config 5 full size, images %s" % pick)
+    # no element of the 1.64 GB left unwritten (poison pattern 0xCDCDCDCD is a float no requant produces here)
+    assert int((dst.view(torch.int32) == -842150451).sum().item()) == 0
+    sub_case = replace(case, bs=4)
+    got_sub, _ = hip.hip_conv(sub_case, dict(data, src=np.ascontiguousarray(data["src"][20:24])))
+    hip.assert_bit_equal(got_sub, dst[20:24].cpu().numpy(), "batch shard [20,24)")
+
+
+def test_config4_shaped_gather_and_concat(hip, oracle):
+    """BASELINE.json configs[3] on ONE GPU: the eight ranks' 16-image s32 outputs of the res2a block (each
+    checked against the oracle) laid out rank-major exactly as the all-gather leaves them
+    (dist.gathered_offsets) -> dfx_concat_submit_gathered at {16,56,56,8x256} + ReLU, against oracle.concat."""
+    import importlib
+    import torch
+    dist = importlib.import_module("deep-fusion_amd.dist")
+    world, per_rank = 8, 16
+    case = replace(C.CONFIG3_SMALL, name="cfg4r", bs=per_rank, relu1=False)   # negative s32 values reach the ReLU
+    data = C.generate(case)
+    rng = np.random.default_rng(77)
+    op = hip.make_conv(case, data)
+    chans = [case.oc1x1] * world
+    offs, total = dist.gathered_offsets(per_rank, case.oh, case.ow, chans, 4)
+    gathered = torch.empty(total, dtype=torch.uint8, device="cuda")
+    shards = []
+    for r in range(world):
+        src_np = rng.integers(0, 17, data["src"].shape, dtype=np.uint8)
+        view = gathered[offs[r]:offs[r] + per_rank * case.oh * case.ow * case.oc1x1 * 4].view(torch.int32)
+        op.submit(torch.from_numpy(src_np).cuda(), view.view(per_rank, case.oh, case.ow, case.oc1x1))
+        torch.cuda.synchronize()
+        shard = view.view(per_rank, case.oh, case.ow, case.oc1x1).cpu().numpy()
+        if r in (0, 7):
+            hip.assert_bit_equal(shard, hip.oracle_conv(oracle, case, dict(data, src=src_np)), "rank %d conv" % r)
+        shards.append(shard)
+    op.close()
+    assert min(int(s.min()) for s in shards) < 0
+    cat = hip.dfa.Concat(per_rank, case.oh, case.ow, chans, np.int32, True)
+    dst = torch.empty(cat.dst_shape, dtype=torch.int32, device="cuda")
+    dst.view(torch.uint8).fill_(0xCD)
+    cat.submit_gathered(gathered, offs, dst)
+    torch.cuda.synchronize()
+    hip.assert_bit_equal(dst.cpu().numpy(), oracle.concat(shards, True), "configs[3] gathered concat")
+
+
 def test_concat(hip, oracle):
     import torch
     from test_oracle import CONCAT_SHAPES, CONCAT_NARROW, concat_inputs
@@ -576,31 +641,84 @@ def test_repeated_submits_rearm_queue(hip, oracle):
         op.close()
 
 
-def test_concurrent_submits_on_several_streams(hip, oracle):
-    """one handle, launches in flight on four streams at once (include/dfx.h: up to 16 per handle): every
-    launch has its own argument block and queue words, so the outputs must not mix.  Different inputs
-    per launch; the resident-weight kernel (device queue: many units per loader) and a streamed one."""
+def test_concurrent_submits_on_several_streams(hip, oracle, tuning):
+    """one handle, launches in flight on many streams at once: every launch has its own argument block and its
+    own slot of the 16-entry queue ring (include/dfx.h), so the outputs must not mix.  20 streams x 3 launches =
+    60 launches wrap the ring several times: a launch whose slot was last used on another stream waits for that
+    launch on the device (slot events) instead of sharing its queue words.  Different inputs per stream; the
+    resident-weight kernel (device queue: many units per loader), a streamed one, and a split op submitted
+    first on the default stream and then on side streams."""
     import torch
-    for case in (C.ConvCase("conc_q", 6, 32, 120, 96, 64, 0, dst_dt=C.F32), replace(C.CONFIG3_SMALL, bs=5, dst_dt=C.U8),
-                 C.ConvCase("conc_s", 3, 128, 14, 14, 128, 256, dst_dt=C.S32)):
+    cases = [(C.ConvCase("conc_q", 6, 32, 120, 96, 64, 0, dst_dt=C.F32), 20, None),
+             (replace(C.CONFIG3_SMALL, bs=5, dst_dt=C.U8), 20, None),
+             (C.ConvCase("conc_s", 3, 128, 14, 14, 128, 256, dst_dt=C.S32), 4, None),
+             (C.ConvCase("conc_split", 2, 128, 7, 7, 256, 256, dst_dt=C.U8), 4, "DFX_STREAM_SPLIT")]
+    for case, nstreams, switch in cases:
+        if switch:
+            tuning.setenv(switch, "1")
         data = C.generate(case)
         op = hip.make_conv(case, data)
+        if switch:
+            assert op.info().kernel_name.decode().startswith("split:"), op.info().kernel_name
         rng = np.random.default_rng(11)
-        srcs_np = [rng.integers(0, 256, data["src"].shape).astype(np.uint8) for _ in range(4)]
+        nsrc = min(nstreams, 5)   # distinct inputs (stream i uses input i % nsrc)
+        srcs_np = [rng.integers(0, 256, data["src"].shape).astype(np.uint8) for _ in range(nsrc)]
         refs = [hip.oracle_conv(oracle, case, dict(data, src=sn)) for sn in srcs_np]
-        streams = [torch.cuda.Stream() for _ in range(4)]
+        streams = [None if (switch and i == 0) else torch.cuda.Stream() for i in range(nstreams)]
         tdt = {C.F32: torch.float32, C.S32: torch.int32, C.S8: torch.int8, C.U8: torch.uint8}[case.dst_dt]
         srcs = [torch.from_numpy(sn).cuda() for sn in srcs_np]
-        outs = [[torch.empty(op.dst_shape, dtype=tdt, device="cuda") for _ in range(3)] for _ in range(4)]
+        outs = [[torch.empty(op.dst_shape, dtype=tdt, device="cuda") for _ in range(3)] for _ in range(nstreams)]
+        for row in outs:
+            for o in row:
+                o.view(torch.uint8).fill_(0xCD)
         torch.cuda.synchronize()
         for rep in range(3):
             for i, st in enumerate(streams):
-                op.submit(srcs[i], outs[i][rep], stream=st)
+                op.submit(srcs[i % nsrc], outs[i][rep], stream=st)
         torch.cuda.synchronize()
-        for i in range(4):
+        for i in range(nstreams):
             for rep in range(3):
-                hip.assert_bit_equal(outs[i][rep].cpu().numpy(), refs[i], "stream %d launch %d %s" % (i, rep, case.name))
+                hip.assert_bit_equal(outs[i][rep].cpu().numpy(), refs[i % nsrc],
+                                     "stream %d launch %d %s" % (i, rep, case.name))
         op.close()
+        if switch:
+            tuning.setenv(switch, None)
+
+
+def test_concurrent_submits_from_two_host_threads(hip, oracle):
+    """include/dfx.h: a handle may be submitted from several host threads.  Two threads, each with its own
+    stream and input, 24 launches each (the ring wraps three times)."""
+    import threading
+    import torch
+    case = replace(C.CONFIG3_SMALL, bs=5, dst_dt=C.U8)
+    data = C.generate(case)
+    op = hip.make_conv(case, data)
+    rng = np.random.default_rng(12)
+    srcs_np = [rng.integers(0, 256, data["src"].shape).astype(np.uint8) for _ in range(2)]
+    refs = [hip.oracle_conv(oracle, case, dict(data, src=sn)) for sn in srcs_np]
+    srcs = [torch.from_numpy(sn).cuda() for sn in srcs_np]
+    outs = [[torch.empty(op.dst_shape, dtype=torch.uint8, device="cuda") for _ in range(24)] for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    torch.cuda.synchronize()
+    errs = []
+
+    def work(i):
+        try:
+            for o in outs[i]:
+                op.submit(srcs[i], o, stream=streams[i])
+        except Exception as e:  # noqa: BLE001 - reported below
+            errs.append(e)
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for i in range(2):
+        for k, o in enumerate(outs[i]):
+            hip.assert_bit_equal(o.cpu().numpy(), refs[i], "thread %d launch %d" % (i, k))
+    op.close()
 
 
 @pytest.mark.parametrize("geom", ["1,56", "2,56", "3,56", "4,56", "3,32", "4,32", "2,32", "7,32"])
