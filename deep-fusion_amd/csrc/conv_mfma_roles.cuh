@@ -1,0 +1,723 @@
+// conv_mfma_roles.cuh -- the fused u8 x s8 conv3x3 + ReLU + requant + conv1x1 (+ReLU) + requant
+// block with 1-byte output, as a pipeline of SPECIALISED waves inside one persistent workgroup per CU
+// (gfx950 / CDNA4).  Same arithmetic, LDS image, unit / tile protocol and loader as conv_mfma.cuh; what
+// changes is who does what.
+//
+// Replaces (like conv_mfma.cuh):
+//   compute_loop / store_output        /root/reference/src/jit_conv_kernel.cc:317-393, :218-305
+//   compute1x1_loop / store_1x1output  src/jit_conv_kernel.cc:143-191, :50-141
+//   infer_conv0conv1                   src/op_conv.cc:140-260
+//
+// Why: in conv_mfma.cuh every compute wave walks conv0 (36 MFMAs, LDS-fed) -> requant 0 -> conv1 (16
+// MFMAs) -> requant 1 + stores (256 VALU + 32 stores) one after the other, with ~120 live VGPRs in each
+// phase.  A wave issues in order, so its matrix work and its vector work never overlap, every phase
+// change exposes an LDS round trip (first fragments, 1x1 weights twice, constants), and what overlap
+// there is comes from four waves per SIMD happening to be in different phases: measured 17 % MFMA/VALU
+// co-execution, 27 % matrix-pipe utilisation (round 2: profiles/r02_res2a_u8_rocprofv3_summary.txt).
+// Here the phases are ROLES with their own waves, so a SIMD always holds a matrix-heavy wave next to
+// vector-heavy ones:
+//   * 4 A waves (one per SIMD): conv0 + requant 0.  36 MFMAs per 32-pixel tile back to back, fragments
+//     prefetched through a register ring, accumulators started from resident registers (the MFMA's C
+//     operand) -- no LDS round trip between tiles.  The u8 intermediate (32 pixels x OC bytes = 2 KB, in
+//     the 1x1 MFMA's A-fragment order) goes to a ring of `mid` slots in LDS.  The reference keeps it in
+//     xmm registers (jit_conv_kernel.cc:275-277); here it crosses from one wave's registers to another's
+//     through LDS and never reaches HBM either.
+//   * 6 B waves: conv1 + requant 1 + stores.  The 1x1 weights (OC1 x OC bytes = 64 VGPRs per lane at the
+//     headline shape) stay RESIDENT IN REGISTERS for the whole launch, so a B wave's only LDS traffic per
+//     tile is the 2 KB of `mid`, its constants and three control words.
+//   * 2 loader waves: unchanged (global -> registers -> LDS halo tiles, units from the static split /
+//     device queue).
+//   12 waves x <= 168 VGPRs (3 per SIMD).  LDS traffic per tile drops from 72 KB to 57 KB (no 1x1 weight
+//   or start-value re-reads).
+// Hand-offs are LDS words written and read by whole waves, all control flow scalar (see conv_mfma.cuh):
+//   A: tile claim (ds_append CTL_NEXT) -> conv0 -> count the tile off its input slot (CTL_DONE) ->
+//      requant 0 -> mid slot m = ds_append(MHEAD), wait MFREE[m % NM] -> write mid + {dst pixel, valid
+//      pixels} -> MFULL[m % NM] = generation + 1.
+//   B: b = ds_append(MTAIL) -> wait MFULL[b % NM] -> read mid -> MFREE[b % NM] = generation + 1 -> per
+//      group of 128 output channels: 2 x 4 MFMAs from registers, requant 1 (emit_pair of conv_mfma.cuh),
+//      16 dword stores (a half-wave writes one whole 128-byte line).
+//   End: an A wave that runs out of tiles adds itself to ADONE; a B wave whose claim lies beyond the final
+//      MHEAD leaves.  Every spin is bounded (MFMA_SPIN_LIMIT).
+// The mid ring lives in the LDS area of the packed 1x1 weights, which is dead once every B wave has
+// copied its fragments to registers (W1DONE).
+//
+// Requant: stage 0 takes the host-proven "fma" mode only (geom.mode0 == 3): accumulators start from
+// bits(2^23) + comp + bias, so their bits read as the float 2^23 + t for the true sum t = acc + bias >= 0
+// and as 2^23 - |t|/2 (the binade below: still negative after the subtraction) for t < 0; one
+// v_pk_fma_f32(x, s, -2^23 s) then yields t*s with the reference's single rounding (2^23 s is exact) for
+// t >= 0 and some negative number for t < 0, which the stage's ReLU + unsigned saturation turns into 0
+// exactly as they do the reference's negative product -- 1.5 VALU instructions per value instead of 2.
+// Needs s >= 0.  Stage 1 takes the "magic" mode of conv_mfma.cuh (geom.mode1 == 2).  Everything else (exact
+// x86 overflow semantics, round-down, negative scales, 4-byte outputs) stays on conv_mfma.cuh.
+//
+// Supported: what conv_mfma.cuh supports, with oc1x1 a multiple of 128 and (oc1x1 / 32) * (oc / 32) <= 16.
+#pragma once
+
+#include "conv_mfma.cuh"
+
+namespace dfx {
+
+constexpr int RL_A = 4;                              // conv0 waves
+constexpr int RL_B = 6;                              // conv1 + store waves
+constexpr int RL_C = RL_A + RL_B;                    // waves that stage the weights
+constexpr int RL_WAVES = RL_C + MFMA_TEAMS;          // + 2 loaders
+constexpr int RL_THREADS = 64 * RL_WAVES;            // 768
+constexpr int RL_CTRL_BYTES = 512;                   // control block: the words of conv_mfma.cuh + the mid ring's
+constexpr int MAGIC3_BITS = 0x4B000000;              // 2^23: stage-0 accumulator start of the "fma" mode
+
+// control words (ints) behind those of conv_mfma.cuh (CTL_*, < 32)
+constexpr int RCTL_MHEAD = 32;   // 64 x mid slots claimed by A waves
+constexpr int RCTL_ADONE = 33;   // 64 x A waves that have left
+constexpr int RCTL_W1DONE = 34;  // 64 x B waves that hold their 1x1 fragments in registers
+constexpr int RCTL_MTAIL = 36;   // [4] per channel group: 64 x mid slots claimed by the group's B waves
+constexpr int RCTL_MFULL = 40;   // [8] generations published into mid slot s
+constexpr int RCTL_MFREE = 48;   // [8] 64 x reads of mid slot s counted off (NCG per generation: one per channel group)
+constexpr int RCTL_MINFO = 64;   // [8][4] per mid slot: dst pixel index of the tile's first pixel, valid pixels
+
+// Stamps build only (make stamps; never quote its run time): every wave keeps cycle sums in scalar registers and
+// writes them at exit to g.prof[(workgroup * 16 + wave) * 16 + k]; profiles/stamps_roles.py prints them.
+#ifdef DFX_STAMPS
+#define RL_SUMS unsigned long long rl_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define RL_ADD(k, v) rl_sum[k] += (v)
+#define RL_FLUSH(role)                                                                                   \
+  do {                                                                                                   \
+    unsigned long long rt_;                                                                              \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt_)::"memory");                      \
+    const unsigned long long te_ = dfx_stamp();                                                          \
+    if (lane == 0) {                                                                                     \
+      unsigned long long *o_ = g.prof + ((size_t)blockIdx.x * 16 + wave) * 16;                           \
+      for (int k_ = 0; k_ < 12; ++k_) o_[k_] = rl_sum[k_];                                               \
+      o_[12] = t_entry; o_[13] = te_; o_[14] = rt_; o_[15] = (role);                                     \
+    }                                                                                                    \
+  } while (0)
+#else
+#define RL_SUMS
+#define RL_ADD(k, v)
+#define RL_FLUSH(role)
+#endif
+
+template <int ICB, int OCB, int NCB, int DST>
+__global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs a, MfmaGeom g) {
+  constexpr int IC = 32 * ICB, OC = 32 * OCB, CP = IC / 16, G = 4, NCG = NCB / G, OC1 = 32 * NCB;
+  constexpr int NM = NCB >= 8 ? 8 : 4, LOG_NM = NCB >= 8 ? 3 : 2;  // mid slots (OCB KB each) inside the W1 area
+  static_assert(DST == DFX_U8 || DST == DFX_S8, "1-byte outputs");
+  static_assert(NCB % G == 0 && NCG <= 4 && NCG <= RL_B && NM <= NCB, "one B wave per group of 128 output channels");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  DFX_STAMP(t_entry);
+  RL_SUMS;
+
+  // LDS: [control block | W0 fragments | W1 fragments -> mid ring | constants | MFMA_NB input tiles]
+  int *ctrl = reinterpret_cast<int *>(smem);
+  unsigned char *w0s = smem + RL_CTRL_BYTES;                   // [OCB][9][ICB][64 lanes][16 B]
+  unsigned char *w1s = w0s + OCB * 9 * ICB * 1024;             // [NCB][OCB][64 lanes][16 B]
+  float *cst = reinterpret_cast<float *>(w1s + NCB * OCB * 1024);
+  constexpr int cst_bytes = (mfma_cst_floats(OC, OC1) * 4 + 15) & ~15;
+  unsigned char *tiles = reinterpret_cast<unsigned char *>(cst) + cst_bytes;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int LW = g.tw + 2;
+  const int upi = g.uy * g.ux;
+  // Workgroup id with XCD-major numbering: hardware deals workgroups round-robin over the 8 XCDs, so the
+  // units of consecutive ids -- vertical neighbours that share two halo rows -- land on eight different L2s
+  // and every halo row is fetched from HBM twice.  Renumbered (blockIdx % 8 picks the group, speed only),
+  // neighbours run on one XCD in the same round and the second reader hits in L2.
+  const int wg = (gridDim.x % 8 == 0) ? (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8)
+                                      : (int)blockIdx.x;
+
+  const v4i x80 = v4i{(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
+  // ---- halo-tile / unit helpers: as in conv_mfma.cuh ----
+  auto load_granule = [&](const uint8_t *src_n, int y0, int x0, int q) {
+    const int lr = (int)__umulhi((unsigned)q, g.row_magic);
+    const int c = q - lr * g.row_chunks;
+    const int X = c / CP, j = (c % CP) ^ chunk_swizzle<CP>(X);
+    const int iy = y0 + lr, ix = x0 + X;
+    const bool ok = iy >= 0 && iy < a.ih && ix >= 0 && ix < a.iw;
+    const int cy = min(max(iy, 0), a.ih - 1), cx = min(max(ix, 0), a.iw - 1);
+    const unsigned off = (unsigned)((cy * a.iw + cx) * IC + 16 * j);
+    const v4i v = *reinterpret_cast<const v4i *>(src_n + off);
+    return (ok ? v : v4i{0, 0, 0, 0}) ^ x80;  // stored form: u8 - 128; padding = 0x80
+  };
+  auto unit_split = [&](int unit, int &n, int &uyi, int &uxi) {
+    n = g.upi_magic ? (int)__umulhi((unsigned)unit, g.upi_magic) : unit;
+    const int u = unit - n * upi;
+    uyi = g.ux_magic ? (int)__umulhi((unsigned)u, g.ux_magic) : u;
+    uxi = u - uyi * g.ux;
+  };
+  auto unit_origin = [&](int unit, const uint8_t *&src_n, int &y0, int &x0) {
+    int n, uyi, uxi;
+    unit_split(unit, n, uyi, uxi);
+    y0 = uyi * g.th - a.pt;
+    x0 = uxi * g.tw - a.pl;
+    src_n = a.src + (size_t)n * a.ih * a.iw * IC;
+  };
+  auto unit_info = [&](int unit, int &pix0, int &thtw, int &tprm) {
+    int n, uyi, uxi;
+    unit_split(unit, n, uyi, uxi);
+    const int y0 = uyi * g.th, x0 = uxi * g.tw;
+    const int th = min(g.th, a.oh - y0), tw = min(g.tw, a.ow - x0);
+    const int tpr = (tw + 31) >> 5;
+    pix0 = (n * a.oh + y0) * a.ow + x0;
+    thtw = (th << 16) | tw;
+    tprm = tpr > 1 ? (int)(((1ull << 32) + tpr - 1) / tpr) : 0;
+  };
+  auto stream_id = [&](int tm) { return tm * (int)gridDim.x + wg; };
+  const bool coop0 = g.static_rounds >= 1;
+  const bool coop1 = g.static_rounds >= 2;
+  auto ctl_load = [&](int idx) {
+    return __builtin_amdgcn_readfirstlane(
+        __hip_atomic_load(ctrl + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+  };
+  auto ctl_store = [&](int idx, int v) {
+    __hip_atomic_store(ctrl + idx, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+
+  if (wave >= RL_C) {
+    // =========================== loader wave `team` (conv_mfma.cuh's, unchanged) ===========================
+    const int team = wave - RL_C;
+#ifndef DFX_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    v4i pf[MFMA_LC];
+    static_assert(MFMA_LC % 2 == 0, "rel table packs two entries per register");
+    unsigned relp[MFMA_LC / 2];
+#pragma unroll
+    for (int i = 0; i < MFMA_LC; ++i) {
+      const int q = min(lane + 64 * i, g.tile_chunks - 1);
+      const int lr = (int)__umulhi((unsigned)q, g.row_magic);
+      const int c = q - lr * g.row_chunks;
+      const int X = c / CP;
+      const unsigned r16 = (unsigned)((lr * a.iw + X) * CP + ((c % CP) ^ chunk_swizzle<CP>(X)));
+      if (i % 2 == 0) relp[i / 2] = r16 & 0xffffu;
+      else relp[i / 2] |= r16 << 16;
+    }
+    const int pad_half = (g.th + 2) * CP;
+    int padoff[2], padside[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int e = lane + 64 * m, side = e >= pad_half ? 1 : 0, r = e - side * pad_half;
+      padside[m] = e < 2 * pad_half ? side : 2;  // 2 = no entry
+      padoff[m] = (((r / CP) * LW + (side ? LW - 1 : 0)) * CP + (r % CP)) * 16;
+    }
+    const bool fast_ok = 2 * pad_half <= 128 && (g.th + 2) * a.iw * CP < 65536;
+    auto unit_fast = [&](int unit, const uint8_t *&base_u, int &left, int &right) {
+      const uint8_t *src_n;
+      int y0, x0;
+      unit_origin(unit, src_n, y0, x0);
+      base_u = src_n + ((long long)y0 * a.iw + x0) * IC;
+      left = x0 < 0;
+      right = x0 + LW - 1 >= a.iw;
+      return fast_ok && y0 >= 1 && y0 + g.th + 1 <= a.ih - 2 && x0 >= -1 && x0 + LW - 1 <= a.iw;
+    };
+    int cur_fast = 0, cur_left = 0, cur_right = 0;
+#define DFX_PREFETCH(UNIT)                                                              \
+  do {                                                                                  \
+    const uint8_t *base_u_;                                                             \
+    cur_fast = unit_fast((UNIT), base_u_, cur_left, cur_right) ? 1 : 0;                 \
+    if (cur_fast) {                                                                     \
+      _Pragma("unroll") for (int i = 0; i < MFMA_LC; ++i) {                             \
+        unsigned rp_ = relp[i / 2];                                                     \
+        asm volatile("" : "+v"(rp_));                                                   \
+        pf[i] = *reinterpret_cast<const v4i *>(base_u_ + ((i % 2 ? rp_ >> 16 : rp_ & 0xffffu) << 4)); \
+      }                                                                                 \
+    } else {                                                                            \
+      const uint8_t *src_n_;                                                            \
+      int y0_, x0_;                                                                     \
+      unit_origin((UNIT), src_n_, y0_, x0_);                                            \
+      int lq_ = lane;                                                                   \
+      asm volatile("" : "+v"(lq_));                                                     \
+      _Pragma("unroll") for (int i = 0; i < MFMA_LC; ++i)                               \
+          pf[i] = load_granule(src_n_, y0_, x0_, min(lq_ + 64 * i, g.tile_chunks - 1)) ^ x80; \
+    }                                                                                   \
+  } while (0)
+    const int T = (int)gridDim.x * MFMA_TEAMS, tg = stream_id(team);
+    const bool use_queue = g.static_rounds * T < g.total_units;
+    auto unit_at = [&](int j) {
+      int v = j * T + tg;
+      if (j >= g.static_rounds) {
+        v = 0x7fffffff;
+        if (use_queue && lane == 0) v = g.static_rounds * T + atomicAdd(g.queue, 1);
+      }
+      return v;
+    };
+    auto write_tile = [&](unsigned char *ins) {
+      {
+        unsigned char *dst = ins + lane * 16;
+        const int dump = g.tile_stride - 1024;
+#pragma unroll
+        for (int i = 0; i < MFMA_LC; ++i)
+          *reinterpret_cast<v4i *>(dst + (64 * i < g.tile_chunks ? 1024 * i : dump)) = pf[i] ^ x80;
+      }
+      if (cur_fast) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          if ((padside[m] == 0 && cur_left) || (padside[m] == 1 && cur_right))
+            *reinterpret_cast<v4i *>(ins + padoff[m]) = x80;
+      }
+    };
+    auto write_rest = [&](unsigned char *ins, int unit) {
+      if (g.tile_chunks > 64 * MFMA_LC) {
+        const uint8_t *src_n; int y0, x0;
+        unit_origin(unit, src_n, y0, x0);
+        for (int q = 64 * MFMA_LC + lane; q < g.tile_chunks; q += 64)
+          *reinterpret_cast<v4i *>(ins + 16 * q) = load_granule(src_n, y0, x0, q);
+      }
+    };
+    int j0 = coop0 ? 1 : 0;
+    if (coop1 && T + tg < g.total_units) {
+      const int u1 = T + tg;
+      unsigned char *ins1 = tiles + (size_t)(2 + team) * g.tile_stride;
+      DFX_PREFETCH(u1);
+      write_tile(ins1);
+      write_rest(ins1, u1);
+      j0 = 2;
+    }
+    if (coop0) __syncthreads();
+    const bool lazy = use_queue && g.lazy_queue;
+    int cur = lazy ? 0 : __builtin_amdgcn_readfirstlane(unit_at(j0));
+    int nxt_v = lazy ? 0 : unit_at(j0 + 1);
+    int jn = j0 + 2;
+    if (!lazy && cur < g.total_units) DFX_PREFETCH(cur);
+    if (!coop0) __syncthreads();  // the only workgroup barrier: weights + control block are in LDS
+
+    RL_ADD(4, dfx_stamp() - t_entry);  // entry -> unit loop (own start-up + the barrier)
+    for (int j = j0;; ++j) {
+      DFX_STAMP(la);
+      const int s = 2 * (j & 1) + team, gen = j >> 1;
+      unsigned char *ins = tiles + (size_t)s * g.tile_stride;
+      if (lazy) {
+        for (int spin = 0; spin < MFMA_SPIN_LIMIT && ctl_load(CTL_DONE + s) < 64 * g.ntu * gen; ++spin)
+          __builtin_amdgcn_s_sleep(8);
+        cur = __builtin_amdgcn_readfirstlane(unit_at(j));
+        if (cur < g.total_units) DFX_PREFETCH(cur);
+      }
+      const bool valid = cur < g.total_units;
+      if (!valid) {
+        if (!(coop0 && j == 1 && tg >= g.total_units)) ctl_store(CTL_END + team, 2 * j + team);
+        break;
+      }
+      for (int spin = 0; spin < MFMA_SPIN_LIMIT && ctl_load(CTL_DONE + s) < 64 * g.ntu * gen; ++spin)
+        __builtin_amdgcn_s_sleep(2);
+      DFX_STAMP(lb);
+      write_tile(ins);
+      write_rest(ins, cur);
+      {
+        int i0, i1, i2;
+        unit_info(cur, i0, i1, i2);
+        ctrl[CTL_INFO + 4 * s + 0] = i0;
+        ctrl[CTL_INFO + 4 * s + 1] = i1;
+        ctrl[CTL_INFO + 4 * s + 2] = i2;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      ctl_store(CTL_FULL + s, gen + 1);
+      DFX_STAMP(lc);
+      if (!lazy) {
+        cur = __builtin_amdgcn_readfirstlane(nxt_v);
+        nxt_v = unit_at(jn++);
+        if (cur < g.total_units) DFX_PREFETCH(cur);
+      }
+      DFX_STAMP(ld);
+      RL_ADD(0, lb - la); RL_ADD(1, lc - lb); RL_ADD(2, ld - lc); RL_ADD(3, 1);  // slot wait, write + publish, draw + prefetch issue, units
+    }
+#undef DFX_PREFETCH
+    RL_FLUSH(2);
+    const int pending = __builtin_amdgcn_readfirstlane(nxt_v);
+    if (use_queue && lane == 0 && pending >= 0) {
+      const int fin = atomicAdd(g.queue + 1, 1);
+      if (fin == (int)gridDim.x * MFMA_TEAMS - 1) {
+        atomicExch(g.queue, 0);
+        atomicExch(g.queue + 1, 0);
+      }
+    }
+    return;
+  }
+
+  // =========================== A and B waves: stage weights, constants, first tiles ===========================
+  {
+    constexpr int NT = RL_C * 64;        // staging threads
+    constexpr int CWT = RL_C / 2;        // waves that stage one first tile
+    constexpr int TT = CWT * 64;
+    const int steam = wave / CWT, ctid = wave * 64 + lane, tctid = (wave % CWT) * 64 + lane;
+    const v4i *s = reinterpret_cast<const v4i *>(a.wei);
+    v4i *d = reinterpret_cast<v4i *>(w0s);
+    const int total = OCB * 9 * ICB * 64 + NCB * OCB * 64 + (mfma_cst_floats(OC, OC1) * 4 + 15) / 16;
+    unsigned char *slot = tiles + (size_t)steam * g.tile_stride;
+    const int unit0 = stream_id(steam);
+    const bool tile0 = coop0 && unit0 < g.total_units;
+    const uint8_t *src_n = a.src;
+    int y0 = 0, x0 = 0;
+    if (tile0) unit_origin(unit0, src_n, y0, x0);
+    for (int base = 0; base < total; base += 4 * NT) {
+      const int q0 = base + ctid, last = total - 1;
+      const v4i t0 = s[min(q0 + 0 * NT, last)];
+      const v4i t1 = s[min(q0 + 1 * NT, last)];
+      const v4i t2 = s[min(q0 + 2 * NT, last)];
+      const v4i t3 = s[min(q0 + 3 * NT, last)];
+      v4i u0 = x80, u1 = x80, u2 = x80, u3 = x80;
+      if (tile0 && base == 0) {
+        u0 = load_granule(src_n, y0, x0, min(tctid + 0 * TT, g.tile_chunks - 1));
+        u1 = load_granule(src_n, y0, x0, min(tctid + 1 * TT, g.tile_chunks - 1));
+        u2 = load_granule(src_n, y0, x0, min(tctid + 2 * TT, g.tile_chunks - 1));
+        u3 = load_granule(src_n, y0, x0, min(tctid + 3 * TT, g.tile_chunks - 1));
+      }
+      d[min(q0 + 0 * NT, last)] = t0;
+      d[min(q0 + 1 * NT, last)] = t1;
+      d[min(q0 + 2 * NT, last)] = t2;
+      d[min(q0 + 3 * NT, last)] = t3;
+      if (tile0 && base == 0) {
+        if (tctid + 0 * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (tctid + 0 * TT)) = u0;
+        if (tctid + 1 * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (tctid + 1 * TT)) = u1;
+        if (tctid + 2 * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (tctid + 2 * TT)) = u2;
+        if (tctid + 3 * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (tctid + 3 * TT)) = u3;
+      }
+    }
+    if (tile0) {
+      for (int base = 4 * TT; base < g.tile_chunks; base += 4 * TT) {
+        const int q0 = base + tctid;
+        const v4i t0 = load_granule(src_n, y0, x0, min(q0 + 0 * TT, g.tile_chunks - 1));
+        const v4i t1 = load_granule(src_n, y0, x0, min(q0 + 1 * TT, g.tile_chunks - 1));
+        const v4i t2 = load_granule(src_n, y0, x0, min(q0 + 2 * TT, g.tile_chunks - 1));
+        const v4i t3 = load_granule(src_n, y0, x0, min(q0 + 3 * TT, g.tile_chunks - 1));
+        if (q0 + 0 * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (q0 + 0 * TT)) = t0;
+        if (q0 + 1 * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (q0 + 1 * TT)) = t1;
+        if (q0 + 2 * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (q0 + 2 * TT)) = t2;
+        if (q0 + 3 * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (q0 + 3 * TT)) = t3;
+      }
+    }
+    if (ctid < RL_CTRL_BYTES / 4) {  // control block (see conv_mfma.cuh); the mid ring's words start at zero
+      int v = 0;
+      if (ctid == CTL_END || ctid == CTL_END + 1) {
+        v = 0x7fffffff;
+        if (coop0 && stream_id(ctid - CTL_END) >= g.total_units) v = ctid - CTL_END;
+      }
+      auto first_unit = [&](int sl) {
+        const int u = (sl >> 1) * (int)gridDim.x * MFMA_TEAMS + stream_id(sl & 1);
+        return (sl < 2 ? coop0 : coop1) && u < g.total_units ? u : -1;
+      };
+      if (ctid >= CTL_FULL && ctid < CTL_FULL + MFMA_NB && first_unit(ctid - CTL_FULL) >= 0) v = 1;
+      if (ctid >= CTL_INFO && ctid < CTL_INFO + 4 * MFMA_NB) {
+        const int u0 = first_unit((ctid - CTL_INFO) >> 2);
+        if (u0 >= 0) {
+          int i0, i1, i2;
+          unit_info(u0, i0, i1, i2);
+          const int f = (ctid - CTL_INFO) & 3;
+          v = f == 0 ? i0 : f == 1 ? i1 : f == 2 ? i2 : 0;
+        }
+      }
+      ctrl[ctid] = v;
+    }
+  }
+  __syncthreads();
+
+  typedef __attribute__((address_space(3))) int lds_int;
+  const bool relu1 = a.relu1 || DST == DFX_U8;
+
+  if (wave >= RL_A) {
+    // =========================== B wave: conv1 + requant 1 + stores ===========================
+    // A B wave serves ONE group of G = 4 column blocks (128 output channels) of every tile, wave j group
+    // j % NCG: its G x OCB weight fragments and its lane's requant constants are loaded once and stay in
+    // registers; a mid slot is read by one wave of every group and free when all NCG have counted it off.
+    const int cg = (wave - RL_A) % NCG;
+    const int *ia1 = reinterpret_cast<const int *>(cst + 3 * OC);
+    const v2f *pb1 = reinterpret_cast<const v2f *>(cst + 3 * OC + OC1), *pc1 = reinterpret_cast<const v2f *>(cst + 3 * OC + 3 * OC1);
+    constexpr unsigned row_bytes = OC1;  // dst bytes per pixel
+    const int l31 = lane & 31, h4 = 4 * (lane >> 5);
+    const int chb = 32 * G * cg + G * l31;  // this lane's first channel
+    v4i w1r[G][OCB];
+#pragma unroll
+    for (int cc = 0; cc < G; ++cc)
+#pragma unroll
+      for (int r = 0; r < OCB; ++r)
+        w1r[cc][r] = *reinterpret_cast<const v4i *>(w1s + ((cg * G + cc) * OCB + r) * 1024 + lane * 16);
+    int ia[G];
+    v2f fb[G], fc[G];
+#pragma unroll
+    for (int cc = 0; cc < G; ++cc) {
+      ia[cc] = ia1[chb + cc];
+      fb[cc] = pb1[chb + cc];
+      fc[cc] = pc1[chb + cc];
+    }
+    // (LDS executes a wave's DS instructions in order: the add below follows the reads above)
+    __hip_atomic_fetch_add(ctrl + RCTL_W1DONE, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // all lanes: + 64
+    const unsigned lane_off = (unsigned)h4 * row_bytes + (unsigned)chb;
+    const unsigned ch_off = (unsigned)chb;
+    // (an ordinary returning add by all 64 lanes, not ds_append: see draw_m in the A wave)
+    auto draw_b = [&]() {
+      return __hip_atomic_fetch_add(ctrl + RCTL_MTAIL + cg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    int b_claim = draw_b();
+    RL_ADD(4, dfx_stamp() - t_entry);  // entry -> tile loop
+    for (;;) {
+      DFX_STAMP(b0);
+      const int b = __builtin_amdgcn_readfirstlane(b_claim) >> 6;
+      const int bs = b & (NM - 1), bgen = b >> LOG_NM;
+      bool have = false;
+      for (int spin = 0; spin < MFMA_SPIN_LIMIT; ++spin) {
+        if (ctl_load(RCTL_MFULL + bs) >= bgen + 1) { have = true; break; }
+        // every A wave has left (each published all of its tiles first): MHEAD is final
+        if (ctl_load(RCTL_ADONE) >= 64 * RL_A && (ctl_load(RCTL_MHEAD) >> 6) <= b) {
+          have = ctl_load(RCTL_MFULL + bs) >= bgen + 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (!have) break;
+      DFX_STAMP(b1);
+      const unsigned char *mslot = w1s + bs * (OCB * 1024);
+      v4i mid[OCB];
+#pragma unroll
+      for (int r = 0; r < OCB; ++r) mid[r] = *reinterpret_cast<const v4i *>(mslot + r * 1024 + lane * 16);
+      const int obase_i = __builtin_amdgcn_readfirstlane(
+          __hip_atomic_load(ctrl + RCTL_MINFO + 4 * bs + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      const int nvalid = __builtin_amdgcn_readfirstlane(
+          __hip_atomic_load(ctrl + RCTL_MINFO + 4 * bs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      // this wave is done with the slot once its reads have returned (in-order LDS: the info words came last)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(ctrl + RCTL_MFREE + bs, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // all lanes: + 64
+      b_claim = draw_b();  // the next claim travels while this tile is computed
+      unsigned char *tile_dst = reinterpret_cast<unsigned char *>(a.dst) + (size_t)obase_i * row_bytes;
+      v16i acc1[G];
+#pragma unroll
+      for (int r = 0; r < OCB; ++r)
+#pragma unroll
+        for (int cc = 0; cc < G; ++cc)
+          acc1[cc] = r == 0 ? mfma_i8_from_magic(mid[0], w1r[cc][0]) : mfma_i8(mid[r], w1r[cc][r], acc1[cc]);
+      if (OCB == 1) asm volatile("s_nop 7\n\ts_nop 4" ::: "memory");  // (asm MFMA results: see conv_mfma.cuh)
+      unsigned rb = row_bytes;
+      int nv1 = nvalid - 1;
+      asm volatile("" : "+s"(rb), "+s"(nv1));
+      using T = std::true_type;
+      using F = std::false_type;
+      auto emit = [&](auto check_tag) {
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+          const int pl = 8 * (e >> 2) + (e & 3);  // + 4h: pixel of register e; e + 1 is the next pixel
+          unsigned char *p0, *p1;
+          bool w0 = true, w1 = true;
+          if (decltype(check_tag)::value) {  // partial tile: pixels beyond its end are not written
+            w0 = pl + h4 <= nv1;
+            w1 = pl + 1 + h4 <= nv1;
+            p0 = tile_dst + ((unsigned)min(pl + h4, nv1) * rb + ch_off);
+            p1 = tile_dst + ((unsigned)min(pl + 1 + h4, nv1) * rb + ch_off);
+          } else {  // scalar pixel base + one per-lane offset
+            p0 = (tile_dst + (size_t)((unsigned)pl * rb)) + (size_t)lane_off;
+            p1 = (tile_dst + (size_t)((unsigned)(pl + 1) * rb)) + (size_t)lane_off;
+          }
+          emit_pair<DST, G, 2>(p0, p1, acc1, e, ia, fb, fc, relu1, a.rm1, w0, w1);
+        }
+      };
+      if (nvalid == 32) emit(F{}); else emit(T{});
+      DFX_STAMP(b2);
+      RL_ADD(0, b1 - b0); RL_ADD(1, b2 - b1); RL_ADD(3, 1);  // wait for a mid slot, conv1 + requant 1 + store issue, tiles
+    }
+    RL_FLUSH(1);
+    return;
+  }
+
+  // =========================== A wave: conv0 + requant 0 -> mid ring ===========================
+  const int *ia0 = reinterpret_cast<const int *>(cst);
+  const float *fb0 = cst + OC, *fc0 = cst + 2 * OC;  // per conv0 channel: -2^23 * scale, scale
+  const int lds_row = LW * IC;                        // bytes per halo-tile row in LDS
+  // accumulator start values bits(2^23) + comp + bias of this lane's 16 channels per block: resident, the C
+  // operand of each chain's first MFMA
+  v16i start[OCB];
+  {
+    const int h4 = 4 * (lane >> 5);
+#pragma unroll
+    for (int r = 0; r < OCB; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const v4i iv = *reinterpret_cast<const v4i *>(ia0 + 32 * r + 8 * q + h4);
+        start[r][4 * q + 0] = iv[0]; start[r][4 * q + 1] = iv[1];
+        start[r][4 * q + 2] = iv[2]; start[r][4 * q + 3] = iv[3];
+      }
+  }
+  auto draw = [&]() { return __builtin_amdgcn_ds_append((lds_int *)(ctrl + CTL_NEXT)); };
+  // mid-slot claims: an ordinary returning add by all 64 lanes (+64 per claim, lane 0's result = the old value).
+  // ds_append takes its address from M0 and is only relied upon for the word at LDS address 0 (CTL_NEXT).
+  auto draw_m = [&]() {
+    return __hip_atomic_fetch_add(ctrl + RCTL_MHEAD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  struct Look { int full, end; v4i info; };
+  auto look = [&](int sl, int par) {
+    Look l;
+    l.full = __hip_atomic_load(ctrl + CTL_FULL + sl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    l.info[0] = __hip_atomic_load(ctrl + CTL_INFO + 4 * sl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    l.info[1] = __hip_atomic_load(ctrl + CTL_INFO + 4 * sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    l.info[2] = __hip_atomic_load(ctrl + CTL_INFO + 4 * sl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    l.info[3] = 0;
+    l.end = __hip_atomic_load(ctrl + CTL_END + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return l;
+  };
+  auto split = [&](int t, int &k, int &ti) {
+    k = g.ntu == 1 ? t : (int)__umulhi((unsigned)t, g.ntu_magic);
+    ti = t - k * g.ntu;
+  };
+  bool w1_gone = false;  // every B wave holds its 1x1 fragments in registers: the mid ring may be written
+  int c_ahead = 0;
+  int t = __builtin_amdgcn_readfirstlane(draw()) >> 6, k, ti;
+  split(t, k, ti);
+  Look lk = look(k & (MFMA_NB - 1), k & 1);
+  RL_ADD(4, dfx_stamp() - t_entry);  // entry -> tile loop
+  for (;;) {
+    DFX_STAMP(a0);
+    if (t > g.claim_limit) break;  // cannot happen: keeps a logic error from hanging the GPU
+    const int s = k & (MFMA_NB - 1), gen = k >> 2, p = k & 1;
+    bool have = false;
+    v4i info = lk.info;
+    for (int spin = 0; spin < MFMA_SPIN_LIMIT; ++spin) {
+      if (__builtin_amdgcn_readfirstlane(lk.full) >= gen + 1) { have = true; info = lk.info; break; }
+      if (__builtin_amdgcn_readfirstlane(lk.end) <= k) break;
+      __builtin_amdgcn_s_sleep(1);
+      lk = look(s, p);
+    }
+    const int k_cur = k, ti_cur = ti;
+    auto next_claim = [&]() {
+      t = __builtin_amdgcn_readfirstlane(c_ahead) >> 6;
+      split(t, k, ti);
+      lk = look(k & (MFMA_NB - 1), k & 1);
+    };
+    if (!have) {  // stream p has no k-th unit; done when the other stream has none for k + 1 either
+      if (ctl_load(CTL_END + (p ^ 1)) <= k_cur + 1) break;
+      c_ahead = draw();
+      next_claim();
+      continue;
+    }
+    const unsigned char *ins = tiles + (size_t)s * g.tile_stride;
+    const int pix0 = __builtin_amdgcn_readfirstlane(info[0]);
+    const int thtw = __builtin_amdgcn_readfirstlane(info[1]);
+    const int th = thtw >> 16, tw = thtw & 0xffff;
+    const int npx = th * tw;
+    const int tiles_per_row = (tw + 31) >> 5;
+    const int ntiles = g.linear ? (npx + 31) >> 5 : th * tiles_per_row;
+    DFX_STAMP(a1);
+    RL_ADD(0, a1 - a0);  // wait for the tile's unit
+    c_ahead = draw();  // the next tile's claim travels during conv0
+    if (ti_cur < ntiles) {
+      const int m_ahead = draw_m();  // this tile's mid slot, needed after requant 0
+      const int l31 = lane & 31, h = lane >> 5;
+      int ty, tx, nvalid, obase;
+      if (g.linear) {
+        nvalid = min(32, npx - 32 * ti_cur);
+        const int pc = 32 * ti_cur + min(l31, nvalid - 1);
+        ty = tw == 1 ? pc : (int)__umulhi((unsigned)pc, g.tw_magic);
+        tx = pc - ty * tw;
+        obase = pix0 + 32 * ti_cur;
+      } else {
+        const int tprm = __builtin_amdgcn_readfirstlane(info[2]);
+        const int tr = tprm ? (int)__umulhi((unsigned)ti_cur, (unsigned)tprm) : ti_cur, tc = ti_cur - tr * tiles_per_row;
+        nvalid = min(32, tw - 32 * tc);
+        ty = tr;
+        tx = 32 * tc + min(l31, nvalid - 1);
+        obase = pix0 + tr * a.ow + 32 * tc;
+      }
+      nvalid = __builtin_amdgcn_readfirstlane(nvalid);
+      obase = __builtin_amdgcn_readfirstlane(obase);
+      int lane16 = lane * 16;
+      asm volatile("" : "+v"(lane16));  // (keeps LICM from hoisting every weight-fragment address)
+      // per-lane B-fragment addresses for tap row 0: one per (tap column, ic half)
+      int bb[3][ICB];
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int X = tx + dx;
+        const int pb = (ty * LW + X) * IC, sw = chunk_swizzle<CP>(X);
+#pragma unroll
+        for (int c = 0; c < ICB; ++c) bb[dx][c] = pb + 16 * ((2 * c + h) ^ sw);
+      }
+      v16i acc0[OCB];
+      {
+        constexpr int NS = 9 * ICB;  // k-steps
+        constexpr int RD = DFX_RING;
+        v4i fbr[RD], fw[RD][OCB];
+        auto fetch = [&](int st, int slot) {  // st, slot are compile-time after unrolling
+          const int tap = st / ICB, c = st % ICB;
+          fbr[slot] = *reinterpret_cast<const v4i *>(ins + (tap / 3) * lds_row + bb[tap % 3][c]);
+#pragma unroll
+          for (int r = 0; r < OCB; ++r)
+            fw[slot][r] = *reinterpret_cast<const v4i *>(w0s + ((r * 9 + tap) * ICB + c) * 1024 + lane16);
+        };
+#pragma unroll
+        for (int st = 0; st < RD - 1; ++st) fetch(st, st);
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int r = 0; r < OCB; ++r)
+            acc0[r] = mfma_i8(fw[st % RD][r], fbr[st % RD], st == 0 ? start[r] : acc0[r]);  // D0[oc][px]
+          __builtin_amdgcn_sched_barrier(0);
+          if (st + RD - 1 < NS) fetch(st + RD - 1, (st + RD - 1) % RD);
+        }
+      }
+      DFX_STAMP(a2);
+      // every fragment of the tile has been consumed: count this claim off on its input slot
+      __hip_atomic_fetch_add(ctrl + CTL_DONE + s, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // all lanes: + 64
+      next_claim();
+      // ---- requant 0 ("fma" mode) -> A fragments of the 1x1 ----
+      v4i mid[OCB];
+      const int h4 = 4 * h;
+      if (g.s0_uniform) {
+        const v2f sc2 = {g.s0_value, g.s0_value};
+        const v2f cc2 = {-8388608.0f * g.s0_value, -8388608.0f * g.s0_value};
+#pragma unroll
+        for (int r = 0; r < OCB; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            unsigned pk = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+              v2f x = {__int_as_float(acc0[r][4 * q + i]), __int_as_float(acc0[r][4 * q + i + 1])};
+              x = __builtin_elementwise_fma(x, sc2, cc2);
+              pk = __builtin_amdgcn_cvt_pk_u8_f32(x[0], i, pk);
+              pk = __builtin_amdgcn_cvt_pk_u8_f32(x[1], i + 1, pk);
+            }
+            mid[r][q] = (int)(pk ^ 0x80808080u);
+          }
+      } else {
+#pragma unroll
+        for (int r = 0; r < OCB; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const v4f sc = *reinterpret_cast<const v4f *>(fc0 + 32 * r + 8 * q + h4);
+            const v4f cc = *reinterpret_cast<const v4f *>(fb0 + 32 * r + 8 * q + h4);
+            unsigned pk = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+              v2f x = {__int_as_float(acc0[r][4 * q + i]), __int_as_float(acc0[r][4 * q + i + 1])};
+              x = __builtin_elementwise_fma(x, v2f{sc[i], sc[i + 1]}, v2f{cc[i], cc[i + 1]});
+              pk = __builtin_amdgcn_cvt_pk_u8_f32(x[0], i, pk);
+              pk = __builtin_amdgcn_cvt_pk_u8_f32(x[1], i + 1, pk);
+            }
+            mid[r][q] = (int)(pk ^ 0x80808080u);
+          }
+      }
+      DFX_STAMP(a3);
+      // ---- publish into the mid ring ----
+      const int m = __builtin_amdgcn_readfirstlane(m_ahead) >> 6;
+      const int ms = m & (NM - 1), mgen = m >> LOG_NM;
+      if (!w1_gone) {
+        for (int spin = 0; spin < MFMA_SPIN_LIMIT && ctl_load(RCTL_W1DONE) < 64 * RL_B; ++spin) __builtin_amdgcn_s_sleep(1);
+        w1_gone = true;
+      }
+      for (int spin = 0; spin < MFMA_SPIN_LIMIT && ctl_load(RCTL_MFREE + ms) < 64 * NCG * mgen; ++spin) __builtin_amdgcn_s_sleep(1);
+      DFX_STAMP(a4);
+      unsigned char *mslot = w1s + ms * (OCB * 1024);
+#pragma unroll
+      for (int r = 0; r < OCB; ++r) *reinterpret_cast<v4i *>(mslot + r * 1024 + lane16) = mid[r];
+      ctrl[RCTL_MINFO + 4 * ms + 0] = obase;
+      ctrl[RCTL_MINFO + 4 * ms + 1] = nvalid;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // all lanes' writes first
+      ctl_store(RCTL_MFULL + ms, mgen + 1);
+      DFX_STAMP(a5);
+      // address math + conv0, requant 0, wait for a free mid slot, write + publish, tiles
+      RL_ADD(1, a2 - a1); RL_ADD(2, a3 - a2); RL_ADD(5, a4 - a3); RL_ADD(6, a5 - a4); RL_ADD(3, 1);
+    } else {  // a claim beyond its unit's tiles: nothing to compute
+      __hip_atomic_fetch_add(ctrl + CTL_DONE + s, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      next_claim();
+    }
+  }
+  __hip_atomic_fetch_add(ctrl + RCTL_ADONE, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // all lanes: + 64
+  RL_FLUSH(0);
+}
+
+}  // namespace dfx

@@ -26,6 +26,7 @@
 #include "conv_mfma.cuh"
 #include "conv_stream.cuh"
 #include "conv_direct.cuh"
+#include "conv_mfma_roles.cuh"
 #include "dfx_device.cuh"
 
 namespace dfx {
@@ -37,6 +38,8 @@ DFX_DECL(s32);
 DFX_DECL(s8);
 DFX_DECL(u8);
 #undef DFX_DECL
+int launch_conv_mfma_roles_u8(const ConvArgs &, const MfmaGeom &, int, int, int, int, int, hipStream_t, int);
+int launch_conv_mfma_roles_s8(const ConvArgs &, const MfmaGeom &, int, int, int, int, int, hipStream_t, int);
 #define DFX_DECL(n) \
   int launch_conv_mfma_##n##_unfused(const ConvArgs &, const MfmaGeom &, int, int, int, int, hipStream_t, int)
 DFX_DECL(f32);
@@ -91,7 +94,7 @@ static size_t dt_size(int dt) { return (dt == DFX_F32 || dt == DFX_S32) ? 4 : 1;
 // ---- testing / tuning switches.  The environment is read ONCE, when the
 //      library is first used; tests flip a switch afterwards with dfx_debug_set_tuning(). ----
 namespace {
-const char *const kTuningKeys[] = {"DFX_MAX_TH", "DFX_FORCE_GEOM", "DFX_STATIC_ROUNDS", "DFX_NO_FAST", "DFX_NO_MAGIC", "DFX_NO_LAZY", "DFX_STORE_BOUND_BYTES",
+const char *const kTuningKeys[] = {"DFX_MAX_TH", "DFX_FORCE_GEOM", "DFX_STATIC_ROUNDS", "DFX_NO_FAST", "DFX_NO_MAGIC", "DFX_NO_LAZY", "DFX_NO_ROLES", "DFX_STORE_BOUND_BYTES",
                                    "DFX_STREAM_PXB", "DFX_STREAM_BLOCKING", "DFX_STREAM_PLANES", "DFX_STREAM_OCC_PAR",
                                    "DFX_STREAM_SPLIT", "DFX_STREAM_DIRECT", "DFX_STREAM_GRID", "DFX_DEBUG_PTRS",
                                    "DEEPFUSION_PROFILE"};
@@ -155,6 +158,10 @@ struct dfx_conv {
   bool split_recorded;     // a previous submit exists (split_last may legitimately be the NULL stream)
   std::mutex *split_mu;    // split ops: orders concurrent submits from several host threads
   int icb, ocb, G, grid, block, lds;
+  // role-specialised fused kernel (conv_mfma_roles.cuh): roles_ok = the SHAPE fits it (decided at create; LDS is
+  // then sized for its larger control block), roles = the WEIGHTS allow its requant modes (decided by
+  // dfx_conv_set_weights); otherwise the op runs on conv_mfma.cuh's kernel
+  bool roles_ok, roles;
   void *d_wei, *d_wei1, *d_consts;
   int *d_queue;  // MFMA variant: ring of DFX_QUEUE_RING x {next unit, finished loaders}, one slot per launch in flight
   unsigned launch_seq;
@@ -357,10 +364,10 @@ static size_t store_bound_bytes() {
   return 512;
 }
 
-static bool pick_geometry(const dfx_conv_desc &d, MfmaGeom &g, int &lds) {
+static bool pick_geometry(const dfx_conv_desc &d, MfmaGeom &g, int &lds, int ctrl_bytes = MFMA_CTRL_BYTES) {
   const int ICB = d.ic / 32, OCB = d.oc / 32, NCB = d.oc1x1 / 32;
   const size_t fixed = (size_t)OCB * 9 * ICB * 1024 + (size_t)NCB * OCB * 1024 +
-                       round16((size_t)mfma_cst_floats(d.oc, d.oc1x1) * 4) + MFMA_CTRL_BYTES;
+                       round16((size_t)mfma_cst_floats(d.oc, d.oc1x1) * 4) + (size_t)ctrl_bytes;
   const size_t lds_max = 163840;  // one workgroup per CU owns the whole LDS
   if (fixed + 4 * 1024 > lds_max) return false;
   const size_t tile_max = (lds_max - fixed) / MFMA_NB;  // ring of MFMA_NB tile slots
@@ -452,6 +459,13 @@ static bool mfma_eligible(const dfx_conv_desc &d) {  // fused or unfused (oc1x1 
   if ((long long)d.bs * d.oh * d.ow >= (1LL << 31) - 64) return false;  // (pixel indices are 32-bit in the kernel)
   return d.kh == 3 && d.kw == 3 && d.sh == 1 && d.sw == 1 && d.pad_t <= 1 && d.pad_l <= 1 &&
          (d.ic == 32 || d.ic == 64) && (d.oc == 32 || d.oc == 64) && d.oc1x1 % 32 == 0;
+}
+
+// the role-specialised kernel (conv_mfma_roles.cuh): fused, 1-byte output, output channels in groups of 128 (<= 4)
+static bool roles_eligible(const dfx_conv_desc &d) {
+  if (tune("DFX_NO_ROLES") && atoi(tune("DFX_NO_ROLES")) != 0) return false;  // testing aid: conv_mfma.cuh's kernel
+  return mfma_eligible(d) && d.oc1x1 > 0 && !d.fuse_pool && (d.dst_dt == DFX_U8 || d.dst_dt == DFX_S8) &&
+         d.oc1x1 % 128 == 0 && d.oc1x1 / 128 <= 4;
 }
 
 // ---- direct-weight fused kernel (conv_direct.cuh) ----
@@ -627,6 +641,12 @@ static int mfma_dispatch(dfx_conv *h, const ConvArgs &a, const MfmaGeom &g, hipS
       case DFX_U8: return launch_conv_mfma_u8_unfused(a, g, h->icb, h->ocb, h->grid, h->lds, s, mode);
     }
     return -1;
+  }
+  if (h->roles_ok && (mode == 1 || h->roles)) {
+    const int ncb = h->d.oc1x1 / 32;
+    const int rc = h->d.dst_dt == DFX_U8 ? launch_conv_mfma_roles_u8(a, g, h->icb, h->ocb, ncb, h->grid, h->lds, s, mode)
+                                         : launch_conv_mfma_roles_s8(a, g, h->icb, h->ocb, ncb, h->grid, h->lds, s, mode);
+    if (mode != 1 || rc != 0) return rc;  // (mode 1 raises the LDS limit of BOTH kernels)
   }
   switch (h->d.dst_dt) {
     case DFX_F32: return launch_conv_mfma_f32(a, g, h->icb, h->ocb, h->G, h->grid, h->lds, s, mode);
@@ -859,8 +879,9 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
   } else if (d.fuse_pool && !(want_mfma && pick_geometry(d, h->geom, h->lds))) {
     conv_release(h);  // (no other kernel knows about the pooled destination)
     return fail(DFX_ERR_UNSUPPORTED, "conv_create: no unit geometry of the resident-weight kernel fits fused pooling here");
-  } else if (want_mfma && pick_geometry(d, h->geom, h->lds)) {
+  } else if (want_mfma && pick_geometry(d, h->geom, h->lds, roles_eligible(d) ? RL_CTRL_BYTES : MFMA_CTRL_BYTES)) {
     const bool fused = d.oc1x1 > 0;
+    h->roles_ok = roles_eligible(d);
     h->variant = fused ? DFX_VARIANT_MFMA_FUSED : DFX_VARIANT_MFMA_CONV;
     h->icb = d.ic / 32; h->ocb = d.oc / 32;
     const int ncb = d.oc1x1 / 32;
@@ -1288,6 +1309,26 @@ int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei, const void *bia0, con
       else if (mode1 == 2 && !magic1_ok(c1[o1], b1[o1], s1[o1])) mode1 = 1;
     }
     if (no_magic) { mode0 = std::min(mode0, 1); mode1 = std::min(mode1, 1); }
+    // "fma" (stage 0 of the role-specialised kernel, conv_mfma_roles.cuh): accumulator started from
+    // bits(2^23) + comp + bias.  t = acc + bias must stay inside (-2^23, 2^23): non-negative t then reads as the
+    // float 2^23 + t, negative t as 2^23 - |t|/2; fma(x, s, -2^23 s) = t * s with one rounding (2^23 s is exact)
+    // or something negative that the stage's ReLU + u8 saturation turn into 0 like the reference's negative
+    // product -- which needs s >= 0.  bias integer-valued; |acc| <= 2^24 follows (0 is a possible acc).
+    auto fma0_ok = [](const Ch &c, float bias, float scale) {
+      const double b = bias, cb = 128.0 * (c.P - c.N) + b;
+      if (b != std::floor(b) || !(scale >= 0.0f) || !std::isfinite(scale * 8388608.0f)) return false;
+      return -(128.0 * c.P + 127.0 * c.N) + cb > -8388608.0 && 127.0 * c.P + 128.0 * c.N + cb < 8388608.0;
+    };
+    bool roles = h->roles_ok && fused && mode1 == 2 && d.conv0_round_mode == DFX_ROUND_NEAREST && !no_fast && !no_magic;
+    for (int oc = 0; oc < OC && roles; ++oc)
+      if (!fast_ok(c0[oc], b0[oc], s0[oc]) || !fma0_ok(c0[oc], b0[oc], s0[oc])) roles = false;
+    if (roles) mode0 = 3;
+    h->roles = roles;
+    if (h->variant == DFX_VARIANT_MFMA_FUSED) {
+      if (roles) snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_mfma_roles_kernel<%d,%d,%d,%d>", ICB, OCB, NCB, d.dst_dt);
+      else snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_mfma_fused_kernel<%d,%d,%d,%d>", ICB, OCB, G, d.dst_dt);
+      h->block = roles ? RL_THREADS : MFMA_THREADS;
+    }
     // slot A is an integer (bit copy into the f32 array), B and C are floats
     auto put_i = [](float *dst, int32_t v) { memcpy(dst, &v, 4); };
     auto inline_stage = [&](int mode, const Ch &c, float bias, float scale, float *A, float *B, float *C) {
@@ -1304,7 +1345,9 @@ int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei, const void *bia0, con
     for (int oc = 0; oc < OC; ++oc) {
       if (fused) {
         const int32_t comp = (int32_t)(128.0 * (c0[oc].P - c0[oc].N));
-        put_i(comp0 + oc, mode0 == 2 ? MAGIC0_BITS + comp + (int32_t)b0[oc] : comp);  // accumulator start value
+        put_i(comp0 + oc, mode0 == 3 ? MAGIC3_BITS + comp + (int32_t)b0[oc]
+                        : mode0 == 2 ? MAGIC0_BITS + comp + (int32_t)b0[oc] : comp);  // accumulator start value
+        if (mode0 == 3) b0[oc] = -8388608.0f * s0[oc];  // the fma's addend -2^23 * scale (exact)
       } else {
         float A, B, C;
         inline_stage(mode0, c0[oc], b0[oc], s0[oc], &A, &B, &C);

@@ -721,6 +721,73 @@ def test_concurrent_submits_from_two_host_threads(hip, oracle):
     op.close()
 
 
+ROLES_CASES = [
+    replace(C.CONFIG3_SMALL, bs=3, dst_dt=C.U8),                                       # headline shape, 2 channel groups
+    replace(C.CONFIG3_SMALL, bs=3, dst_dt=C.U8, wide=True),                            # saturation on both stages
+    replace(C.CONFIG3_SMALL, bs=2, dst_dt=C.S8, relu1=False, wide=True),               # negative outputs, signed saturation
+    replace(C.CONFIG3_SMALL, bs=2, dst_dt=C.U8, per_channel0=True, per_channel1=True),  # per-channel constants from LDS
+    replace(C.CONFIG3_SMALL, bs=2, dst_dt=C.U8, bia0_dt=C.UNDEF, bia1_dt=C.UNDEF),
+    replace(C.CONFIG3_SMALL, bs=2, dst_dt=C.U8, bia0_dt=C.S8, bia1_dt=C.U8),
+    replace(C.SMALL64, dst_dt=C.U8),                                                   # 12x10: ragged tiles, one channel group
+    replace(C.SMALL64, dst_dt=C.S8, wide=True),
+    C.ConvCase("r32_384", 2, 32, 17, 23, 32, 384, dst_dt=C.U8),                         # ic = oc = 32, three channel groups
+    C.ConvCase("r32_512", 1, 32, 9, 40, 32, 512, dst_dt=C.U8, pad=(0, 0)),              # four groups (two B waves serve two), no padding
+    C.ConvCase("r64_32_128", 2, 64, 8, 70, 32, 128, dst_dt=C.U8, wide=True),           # ic 64 -> oc 32, column-split units
+    C.ConvCase("r32_64_256", 2, 32, 30, 33, 64, 256, dst_dt=C.S8, relu1=True),
+    C.ConvCase("one128", 1, 32, 3, 3, 32, 128, pad=(0, 0), dst_dt=C.U8),               # a single output pixel
+]
+
+
+@pytest.mark.parametrize("case", ROLES_CASES, ids=lambda c: c.ident())
+def test_role_specialised_kernel(hip, oracle, tuning, case):
+    """conv_mfma_roles.cuh (A waves: conv0 + requant 0 -> mid ring in LDS; B waves: conv1 + requant 1 + stores):
+    bit-exact against the oracle, and byte-identical to conv_mfma.cuh's kernel (DFX_NO_ROLES=1)."""
+    data = C.generate(case)
+    got, info = hip.hip_conv(case, data)
+    assert info.kernel_name.decode().startswith("conv_mfma_roles_kernel"), info.kernel_name
+    assert info.block == 768
+    hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), "roles " + case.ident())
+    tuning.setenv("DFX_NO_ROLES", "1")
+    got_old, info_old = hip.hip_conv(case, data)
+    assert info_old.kernel_name.decode().startswith("conv_mfma_fused_kernel"), info_old.kernel_name
+    hip.assert_bit_equal(got_old, got, "roles vs resident kernel")
+
+
+@pytest.mark.parametrize("geom,rounds", [("1,56", None), ("2,56", "0"), ("3,56", "1"), ("7,32", None), ("4,32", "2"), ("4,56", "1")])
+def test_role_specialised_kernel_scheduling(hip, oracle, tuning, geom, rounds):
+    """unit geometries (full-width linear units, column-split units with partial tiles) x unit hand-out (static
+    split, device queue from the first unit on) for the role-specialised kernel; enough images that every
+    loader works through several units and the mid ring wraps many times."""
+    tuning.setenv("DFX_FORCE_GEOM", geom)
+    if rounds is not None:
+        tuning.setenv("DFX_STATIC_ROUNDS", rounds)
+    case = replace(C.CONFIG3_SMALL, bs=24, dst_dt=C.U8, wide=True)
+    data = C.generate(case)
+    got, info = hip.hip_conv(case, data)
+    assert info.kernel_name.decode().startswith("conv_mfma_roles_kernel") and info.rows_per_unit == int(geom.split(",")[0])
+    hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), "roles geom %s rounds %s" % (geom, rounds))
+
+
+def test_role_specialised_kernel_falls_back(hip, oracle, tuning):
+    """what the role-specialised kernel does not take stays on conv_mfma.cuh's kernel: round-down, a negative
+    conv0 scale, the exact-requant switches."""
+    base = replace(C.CONFIG3_SMALL, bs=2, dst_dt=C.U8)
+    for case, sw in ((replace(base, rm0=1), None), (base, "DFX_NO_MAGIC"), (base, "DFX_NO_FAST")):
+        if sw:
+            tuning.setenv(sw, "1")
+        data = C.generate(case)
+        got, info = hip.hip_conv(case, data)
+        assert info.kernel_name.decode().startswith("conv_mfma_fused_kernel"), (info.kernel_name, sw)
+        hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), "fallback")
+        if sw:
+            tuning.setenv(sw, None)
+    data = C.generate(base)
+    data["scales0"] = -data["scales0"]          # negative scale: the fma mode's sign argument does not hold
+    got, info = hip.hip_conv(base, data)
+    assert info.kernel_name.decode().startswith("conv_mfma_fused_kernel"), info.kernel_name
+    hip.assert_bit_equal(got, hip.oracle_conv(oracle, base, data), "negative scale")
+
+
 @pytest.mark.parametrize("geom", ["1,56", "2,56", "3,56", "4,56", "3,32", "4,32", "2,32", "7,32"])
 def test_unit_geometries_and_tile_rotation(hip, oracle, geom, tuning):
     """every unit decomposition the host may pick (full-width linear units, 32-multiple
