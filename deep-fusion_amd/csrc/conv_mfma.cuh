@@ -241,6 +241,16 @@ __device__ __forceinline__ float acc_to_f32(int raw, float comp, float bias) {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// DFX_PACKED_F32 (never defined in the product build): round 2 wrote the requant arithmetic with v_pk_add_f32 /
+// v_pk_mul_f32 to halve its instruction count.  On gfx950 the packed-f32 instructions execute on the MATRIX
+// pipe's side of the SIMD: they do not overlap with MFMAs -- in one wave's stream every one of them adds ~10
+// cycles to an MFMA-paced loop, and issued by another wave of the SIMD they run at 13.8 cycles each beside an
+// MFMA stream -- whereas plain v_add_f32 / v_mul_f32 / v_fma_f32 / v_cvt_pk_u8_f32 hide under it: six per MFMA
+// in the same wave cost nothing, another wave's run at 6.5 cycles each (tools/probe/probe_coexec.hip,
+// profiles/r03/probe_coexec.jsonl).  All requant arithmetic is therefore written with scalar float operations
+// and the library is built with -fno-slp-vectorize so that hipcc does not pack them again;
+// tests/test_isa_hazards_cpu.py checks that no packed-f32 instruction is left in the conv kernels.
+
 #ifndef DFX_RING
 #define DFX_RING 5  // conv0 fragment prefetch depth (k-steps in flight): LDS latency is several hundred cycles under load
 #endif
@@ -269,18 +279,9 @@ __device__ __forceinline__ void store_group(unsigned char *p, const int (&acc)[G
                                             const float (&cp)[G], const float (&bs)[G],
                                             const float (&sc)[G], bool relu, int rm) {
   float f[G];
-  if (FAST) {  // bs holds comp + bias; packed f32 math where G allows (v_pk_add/mul_f32)
-    if (G >= 2) {
+  if (FAST) {  // bs holds comp + bias.  Plain v_add_f32 / v_mul_f32, never the packed forms: see DFX_PACKED_F32
 #pragma unroll
-      for (int c = 0; c < G; c += 2) {
-        v2f x = {__int2float_rn(acc[c]), __int2float_rn(acc[c + 1])};
-        x = (x + v2f{bs[c], bs[c + 1]}) * v2f{sc[c], sc[c + 1]};
-        f[c] = x[0];
-        f[c + 1] = x[1];
-      }
-    } else {
-      f[0] = __fmul_rn(__fadd_rn(__int2float_rn(acc[0]), bs[0]), sc[0]);
-    }
+    for (int c = 0; c < G; ++c) f[c] = __fmul_rn(__fadd_rn(__int2float_rn(acc[c]), bs[c]), sc[c]);
   } else {
 #pragma unroll
     for (int c = 0; c < G; ++c) f[c] = __fmul_rn(acc_to_f32(acc[c], cp[c], bs[c]), sc[c]);
@@ -385,6 +386,9 @@ __device__ __forceinline__ void store_pixel(unsigned char *p, float (&f)[G], boo
         pk |= b << (8 * c);
       }
     }
+#ifdef DFX_X_NOSTORE  // timing experiment only (profiles/scripts/r3_experiments.sh): compute everything, store nothing
+    if (pk != 0x12345678u) return;
+#endif
     if (G == 4) DFX_STORE(reinterpret_cast<unsigned *>(p), pk);
     else if (G == 2) *reinterpret_cast<unsigned short *>(p) = (unsigned short)pk;
     else *p = (uint8_t)pk;
@@ -405,8 +409,11 @@ __device__ __forceinline__ void emit_pair(unsigned char *p0, unsigned char *p1, 
   float f0[G], f1[G];
 #pragma unroll
   for (int c = 0; c < G; ++c) {
-    if (MODE == 2) {
-#ifdef DFX_SCALAR_EMIT  // diagnostic variant: the same arithmetic without packed instructions
+    if (MODE == 3) {  // fb = the exact product (comp + bias - m / ulp) * scale, fc = scale / ulp: one rounding
+      f0[c] = __builtin_fmaf(__int_as_float(acc[c][e]), fc[c][0], fb[c][0]);
+      f1[c] = __builtin_fmaf(__int_as_float(acc[c][e + 1]), fc[c][0], fb[c][0]);
+    } else if (MODE == 2) {
+#ifndef DFX_PACKED_F32  // plain v_add_f32 + v_mul_f32 (see DFX_PACKED_F32 above)
       f0[c] = __fmul_rn(__fadd_rn(__int_as_float(acc[c][e]), fb[c][0]), fc[c][0]);
       f1[c] = __fmul_rn(__fadd_rn(__int_as_float(acc[c][e + 1]), fb[c][0]), fc[c][0]);
 #else
@@ -443,10 +450,8 @@ __device__ __forceinline__ void emit_pool(unsigned char *p, const v16i (&acc)[G]
     for (int q = 0; q < 2; ++q) {
       const int r = e + 8 * q;
       if (MODE == 2) {
-        v2f x = {__int_as_float(acc[c][r]), __int_as_float(acc[c][r + 1])};
-        x = (x + fb[c]) * fc[c];
-        f[2 * q][c] = x[0];
-        f[2 * q + 1][c] = x[1];
+        f[2 * q][c] = __fmul_rn(__fadd_rn(__int_as_float(acc[c][r]), fb[c][0]), fc[c][0]);
+        f[2 * q + 1][c] = __fmul_rn(__fadd_rn(__int_as_float(acc[c][r + 1]), fb[c][0]), fc[c][0]);
       } else {
         f[2 * q][c] = __fmul_rn(__fadd_rn(__int2float_rn(acc[c][r] + ia[c]), fb[c][0]), fc[c][0]);
         f[2 * q + 1][c] = __fmul_rn(__fadd_rn(__int2float_rn(acc[c][r + 1] + ia[c]), fb[c][0]), fc[c][0]);
@@ -1197,36 +1202,37 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
       DFX_LACC(1, c3 - c2);  // conv0 MFMA issue
       // ---- requant 0 in registers -> A fragments of the 1x1 ----
       v4i mid[OCB];
-      if (mode0 == 2 && g.s0_uniform) {  // the same with the op's single scale in scalar registers
-        const v2f sc2 = {g.s0_value, g.s0_value};
+      if (mode0 == 3) {  // "fma": bits = 2^23 + t (t >= 0) or 2^23 - |t| / 2: one v_fma_f32(x, s, -2^23 s), see conv_mfma_roles.cuh
+        const bool uni = g.s0_uniform != 0;
+        const float su = g.s0_value, cu = -8388608.0f * g.s0_value;
 #pragma unroll
         for (int r = 0; r < OCB; ++r)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
+            v4f sc = {su, su, su, su}, cc = {cu, cu, cu, cu};
+            if (!uni) {
+              sc = *reinterpret_cast<const v4f *>(fc0 + 32 * r + 8 * q + h4);
+              cc = *reinterpret_cast<const v4f *>(fb0 + 32 * r + 8 * q + h4);
+            }
             unsigned pk = 0;
 #pragma unroll
-            for (int i = 0; i < 4; i += 2) {
-              v2f x = {__int_as_float(acc0[r][4 * q + i]), __int_as_float(acc0[r][4 * q + i + 1])};
-              x = (x + v2f{-MAGIC0_F, -MAGIC0_F}) * sc2;
-              pk = __builtin_amdgcn_cvt_pk_u8_f32(x[0], i, pk);
-              pk = __builtin_amdgcn_cvt_pk_u8_f32(x[1], i + 1, pk);
-            }
+            for (int i = 0; i < 4; ++i)
+              pk = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(__int_as_float(acc0[r][4 * q + i]), sc[i], cc[i]), i, pk);
             mid[r][q] = (int)(pk ^ 0x80808080u);
           }
       } else if (mode0 == 2) {  // accumulator bits are the float 1.5 * 2^23 + acc + bias: subtract, scale, pack
+        const bool uni = g.s0_uniform != 0;  // (the op's single scale: no per-channel reads)
+        const float su = g.s0_value;
 #pragma unroll
         for (int r = 0; r < OCB; ++r)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const v4f sc = *reinterpret_cast<const v4f *>(fc0 + 32 * r + 8 * q + h4);
+            v4f sc = {su, su, su, su};
+            if (!uni) sc = *reinterpret_cast<const v4f *>(fc0 + 32 * r + 8 * q + h4);
             unsigned pk = 0;
 #pragma unroll
-            for (int i = 0; i < 4; i += 2) {
-              v2f x = {__int_as_float(acc0[r][4 * q + i]), __int_as_float(acc0[r][4 * q + i + 1])};
-              x = (x + v2f{-MAGIC0_F, -MAGIC0_F}) * v2f{sc[i], sc[i + 1]};
-              pk = __builtin_amdgcn_cvt_pk_u8_f32(x[0], i, pk);
-              pk = __builtin_amdgcn_cvt_pk_u8_f32(x[1], i + 1, pk);
-            }
+            for (int i = 0; i < 4; ++i)
+              pk = __builtin_amdgcn_cvt_pk_u8_f32(__fmul_rn(__fadd_rn(__int_as_float(acc0[r][4 * q + i]), -MAGIC0_F), sc[i]), i, pk);
             mid[r][q] = (int)(pk ^ 0x80808080u);
           }
       } else if (mode0 == 1) {  // ReLU + RNE + saturation + pack in one op
@@ -1239,12 +1245,8 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
             const v4f sc = *reinterpret_cast<const v4f *>(fc0 + ch);
             unsigned pk = 0;
 #pragma unroll
-            for (int i = 0; i < 4; i += 2) {
-              v2f x = {__int2float_rn(acc0[r][4 * q + i]), __int2float_rn(acc0[r][4 * q + i + 1])};
-              x = (x + v2f{bs[i], bs[i + 1]}) * v2f{sc[i], sc[i + 1]};
-              pk = __builtin_amdgcn_cvt_pk_u8_f32(x[0], i, pk);
-              pk = __builtin_amdgcn_cvt_pk_u8_f32(x[1], i + 1, pk);
-            }
+            for (int i = 0; i < 4; ++i)
+              pk = __builtin_amdgcn_cvt_pk_u8_f32(__fmul_rn(__fadd_rn(__int2float_rn(acc0[r][4 * q + i]), bs[i]), sc[i]), i, pk);
             mid[r][q] = (int)(pk ^ 0x80808080u);
           }
       } else {

@@ -57,6 +57,9 @@
 
 namespace dfx {
 
+#ifndef RL_RING
+#define RL_RING 5  // conv0 fragment prefetch depth of an A wave (k-steps in flight)
+#endif
 constexpr int RL_A = 4;                              // conv0 waves
 constexpr int RL_B = 6;                              // conv1 + store waves
 constexpr int RL_C = RL_A + RL_B;                    // waves that stage the weights
@@ -73,6 +76,42 @@ constexpr int RCTL_MTAIL = 36;   // [4] per channel group: 64 x mid slots claime
 constexpr int RCTL_MFULL = 40;   // [8] generations published into mid slot s
 constexpr int RCTL_MFREE = 48;   // [8] 64 x reads of mid slot s counted off (NCG per generation: one per channel group)
 constexpr int RCTL_MINFO = 64;   // [8][4] per mid slot: dst pixel index of the tile's first pixel, valid pixels
+// Input-tile slots: the unit record CTL_INFO[slot] = {dst pixel of the unit's first pixel, (th << 16) | tw,
+// ceil(2^32 / tiles per row), generations PUBLISHED} -- the loader writes the first three words, then the fourth;
+// an A wave takes all four with ONE ds_read_b128 (a lane's 16 bytes are read in one LDS cycle: if the fourth word
+// shows the generation it waits for, the three before it belong to that generation).  CTL_FULL is not used here.
+
+// One dword per lane to (uniform base + per-lane byte offset + immediate): the scalar-base form of
+// global_store_dword, so that a store costs no address instruction at all.  (Given `base + lane offset` as a
+// pointer hipcc builds the 64-bit address with a v_lshl_add_u64 per store; a SIMD issues about one instruction
+// per 4 cycles over all of its waves -- SQ_ACTIVE_INST_ANY covers the whole launch -- so every instruction
+// removed from the tile loop shortens the kernel.)  Dword stores need no wait states after them (conv_mfma.cuh).
+template <int IMM>
+__device__ __forceinline__ void store_dword_saddr_nt(const void *sbase, unsigned voff, unsigned data) {
+  static_assert(IMM >= 0 && IMM < 4096, "13-bit signed immediate");
+  asm volatile("global_store_dword %0, %1, %2 offset:%3 nt" ::"v"(voff), "v"(data), "s"(sbase), "n"(IMM) : "memory");
+}
+
+// Control-word updates by LANE 0 ALONE (the wave is fully active at every call site; exec is restored to all
+// ones).  `__hip_atomic_fetch_add` from all 64 lanes is what conv_mfma.cuh uses; hipcc turns it into the same
+// single-lane add, but through v_mbcnt / v_cmp / s_and_saveexec / branch / s_bcnt1 / v_mov -- a dozen instructions
+// per update, four updates per tile here.  `addr` / `val` are VGPRs holding the word's LDS byte address (the control
+// block sits at LDS address 0) and the addend.
+__device__ __forceinline__ void lds_add_lane0(int addr, int val) {
+  asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(addr), "v"(val) : "memory");
+}
+// returning form: the old value arrives in lane 0 of the result some hundred cycles later; lds_rtn_wait() before
+// its first use (hipcc does not count asm-issued LDS operations; its own s_waitcnt lgkmcnt(n) only ever wait
+// longer because of them: a wave's LDS operations complete in order)
+__device__ __forceinline__ int lds_add_rtn_lane0(int addr, int val) {
+  int r;
+  asm volatile("s_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %1, %2\n\ts_mov_b64 exec, -1" : "=v"(r) : "v"(addr), "v"(val) : "memory");
+  return r;
+}
+__device__ __forceinline__ int lds_rtn_wait(int r) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r)::"memory");
+  return __builtin_amdgcn_readfirstlane(r);
+}
 
 // Stamps build only (make stamps; never quote its run time): every wave keeps cycle sums in scalar registers and
 // writes them at exit to g.prof[(workgroup * 16 + wave) * 16 + k]; profiles/stamps_roles.py prints them.
@@ -310,7 +349,7 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
         ctrl[CTL_INFO + 4 * s + 2] = i2;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      ctl_store(CTL_FULL + s, gen + 1);
+      ctl_store(CTL_INFO + 4 * s + 3, gen + 1);
       DFX_STAMP(lc);
       if (!lazy) {
         cur = __builtin_amdgcn_readfirstlane(nxt_v);
@@ -348,42 +387,32 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
     const uint8_t *src_n = a.src;
     int y0 = 0, x0 = 0;
     if (tile0) unit_origin(unit0, src_n, y0, x0);
-    for (int base = 0; base < total; base += 4 * NT) {
-      const int q0 = base + ctid, last = total - 1;
-      const v4i t0 = s[min(q0 + 0 * NT, last)];
-      const v4i t1 = s[min(q0 + 1 * NT, last)];
-      const v4i t2 = s[min(q0 + 2 * NT, last)];
-      const v4i t3 = s[min(q0 + 3 * NT, last)];
-      v4i u0 = x80, u1 = x80, u2 = x80, u3 = x80;
-      if (tile0 && base == 0) {
-        u0 = load_granule(src_n, y0, x0, min(tctid + 0 * TT, g.tile_chunks - 1));
-        u1 = load_granule(src_n, y0, x0, min(tctid + 1 * TT, g.tile_chunks - 1));
-        u2 = load_granule(src_n, y0, x0, min(tctid + 2 * TT, g.tile_chunks - 1));
-        u3 = load_granule(src_n, y0, x0, min(tctid + 3 * TT, g.tile_chunks - 1));
+    // ONE memory round trip: every global load of the weights, the constants and this thread's share of the first
+    // tile is issued before the first LDS write (two dependent passes cost a second ~2 us trip through a cold L2
+    // with all 256 workgroups asking at once).  NW chunks of weights per thread cover 64 KB; more than that (no
+    // supported shape) would take further passes.
+    constexpr int NW = 7, NTL = 5;  // 16-byte chunks per thread: weights + constants, first tile
+    {
+      const int last = total - 1;
+      v4i wv[NW], tv[NTL];
+#pragma unroll
+      for (int i = 0; i < NW; ++i) wv[i] = s[min(ctid + i * NT, last)];
+      if (tile0) {
+#pragma unroll
+        for (int i = 0; i < NTL; ++i) tv[i] = load_granule(src_n, y0, x0, min(tctid + i * TT, g.tile_chunks - 1));
       }
-      d[min(q0 + 0 * NT, last)] = t0;
-      d[min(q0 + 1 * NT, last)] = t1;
-      d[min(q0 + 2 * NT, last)] = t2;
-      d[min(q0 + 3 * NT, last)] = t3;
-      if (tile0 && base == 0) {
-        if (tctid + 0 * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (tctid + 0 * TT)) = u0;
-        if (tctid + 1 * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (tctid + 1 * TT)) = u1;
-        if (tctid + 2 * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (tctid + 2 * TT)) = u2;
-        if (tctid + 3 * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (tctid + 3 * TT)) = u3;
+#pragma unroll
+      for (int i = 0; i < NW; ++i)
+        if (ctid + i * NT < total) d[ctid + i * NT] = wv[i];
+      if (tile0) {
+#pragma unroll
+        for (int i = 0; i < NTL; ++i)
+          if (tctid + i * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (tctid + i * TT)) = tv[i];
       }
-    }
-    if (tile0) {
-      for (int base = 4 * TT; base < g.tile_chunks; base += 4 * TT) {
-        const int q0 = base + tctid;
-        const v4i t0 = load_granule(src_n, y0, x0, min(q0 + 0 * TT, g.tile_chunks - 1));
-        const v4i t1 = load_granule(src_n, y0, x0, min(q0 + 1 * TT, g.tile_chunks - 1));
-        const v4i t2 = load_granule(src_n, y0, x0, min(q0 + 2 * TT, g.tile_chunks - 1));
-        const v4i t3 = load_granule(src_n, y0, x0, min(q0 + 3 * TT, g.tile_chunks - 1));
-        if (q0 + 0 * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (q0 + 0 * TT)) = t0;
-        if (q0 + 1 * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (q0 + 1 * TT)) = t1;
-        if (q0 + 2 * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (q0 + 2 * TT)) = t2;
-        if (q0 + 3 * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (q0 + 3 * TT)) = t3;
-      }
+      for (int q = ctid + NW * NT; q < total; q += NT) d[q] = s[q];  // (larger weight sets: further passes)
+      if (tile0)
+        for (int q = tctid + NTL * TT; q < g.tile_chunks; q += TT)
+          *reinterpret_cast<v4i *>(slot + 16 * q) = load_granule(src_n, y0, x0, q);
     }
     if (ctid < RL_CTRL_BYTES / 4) {  // control block (see conv_mfma.cuh); the mid ring's words start at zero
       int v = 0;
@@ -395,14 +424,13 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
         const int u = (sl >> 1) * (int)gridDim.x * MFMA_TEAMS + stream_id(sl & 1);
         return (sl < 2 ? coop0 : coop1) && u < g.total_units ? u : -1;
       };
-      if (ctid >= CTL_FULL && ctid < CTL_FULL + MFMA_NB && first_unit(ctid - CTL_FULL) >= 0) v = 1;
-      if (ctid >= CTL_INFO && ctid < CTL_INFO + 4 * MFMA_NB) {
+      if (ctid >= CTL_INFO && ctid < CTL_INFO + 4 * MFMA_NB) {  // slots staged before the barrier start out published
         const int u0 = first_unit((ctid - CTL_INFO) >> 2);
         if (u0 >= 0) {
           int i0, i1, i2;
           unit_info(u0, i0, i1, i2);
           const int f = (ctid - CTL_INFO) & 3;
-          v = f == 0 ? i0 : f == 1 ? i1 : f == 2 ? i2 : 0;
+          v = f == 0 ? i0 : f == 1 ? i1 : f == 2 ? i2 : 1;
         }
       }
       ctrl[ctid] = v;
@@ -442,25 +470,25 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
     __hip_atomic_fetch_add(ctrl + RCTL_W1DONE, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // all lanes: + 64
     const unsigned lane_off = (unsigned)h4 * row_bytes + (unsigned)chb;
     const unsigned ch_off = (unsigned)chb;
-    // (an ordinary returning add by all 64 lanes, not ds_append: see draw_m in the A wave)
-    auto draw_b = [&]() {
-      return __hip_atomic_fetch_add(ctrl + RCTL_MTAIL + cg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
+    int v64 = 64;  // (one VGPR for the whole loop)
+    asm volatile("" : "+v"(v64));
+    // (an ordinary returning add, not ds_append: see draw_m in the A wave)
+    auto draw_b = [&]() { return lds_add_rtn_lane0(4 * (RCTL_MTAIL + cg), v64); };
     int b_claim = draw_b();
     RL_ADD(4, dfx_stamp() - t_entry);  // entry -> tile loop
     for (;;) {
       DFX_STAMP(b0);
-      const int b = __builtin_amdgcn_readfirstlane(b_claim) >> 6;
+      const int b = lds_rtn_wait(b_claim) >> 6;
       const int bs = b & (NM - 1), bgen = b >> LOG_NM;
-      bool have = false;
-      for (int spin = 0; spin < MFMA_SPIN_LIMIT; ++spin) {
-        if (ctl_load(RCTL_MFULL + bs) >= bgen + 1) { have = true; break; }
+      bool have = ctl_load(RCTL_MFULL + bs) >= bgen + 1;
+      for (int spin = 0; !have && spin < MFMA_SPIN_LIMIT; ++spin) {
         // every A wave has left (each published all of its tiles first): MHEAD is final
         if (ctl_load(RCTL_ADONE) >= 64 * RL_A && (ctl_load(RCTL_MHEAD) >> 6) <= b) {
           have = ctl_load(RCTL_MFULL + bs) >= bgen + 1;
           break;
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(4);
+        have = ctl_load(RCTL_MFULL + bs) >= bgen + 1;
       }
       if (!have) break;
       DFX_STAMP(b1);
@@ -468,15 +496,22 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
       v4i mid[OCB];
 #pragma unroll
       for (int r = 0; r < OCB; ++r) mid[r] = *reinterpret_cast<const v4i *>(mslot + r * 1024 + lane * 16);
-      const int obase_i = __builtin_amdgcn_readfirstlane(
-          __hip_atomic_load(ctrl + RCTL_MINFO + 4 * bs + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-      const int nvalid = __builtin_amdgcn_readfirstlane(
-          __hip_atomic_load(ctrl + RCTL_MINFO + 4 * bs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-      // this wave is done with the slot once its reads have returned (in-order LDS: the info words came last)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __hip_atomic_fetch_add(ctrl + RCTL_MFREE + bs, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // all lanes: + 64
+      // (through an LDS-address-space pointer: a volatile vector load through a generic pointer becomes a FLAT load
+      // plus s_waitcnt vmcnt(0), i.e. a wait for every store in flight)
+      typedef int v2i __attribute__((ext_vector_type(2)));
+      typedef __attribute__((address_space(3))) const volatile v2i lds_v2i;
+      const v2i minfo = *(lds_v2i *)(ctrl + RCTL_MINFO + 4 * bs);
+      // this wave is done with the slot once its reads have returned: LDS serves a wave's operations in order, so
+      // the add (and the next claim behind it) cannot overtake them
+      lds_add_lane0(4 * (RCTL_MFREE + bs), v64);
       b_claim = draw_b();  // the next claim travels while this tile is computed
+      const int obase_i = __builtin_amdgcn_readfirstlane(minfo.x);
+      const int nvalid = __builtin_amdgcn_readfirstlane(minfo.y);
+#ifndef DFX_X_LOCALSTORE
       unsigned char *tile_dst = reinterpret_cast<unsigned char *>(a.dst) + (size_t)obase_i * row_bytes;
+#else  // timing experiment only: every tile of a workgroup is written to the same 8 KB (stays in L2, no HBM writes)
+      unsigned char *tile_dst = reinterpret_cast<unsigned char *>(a.dst) + (size_t)blockIdx.x * 32 * row_bytes + (obase_i & 0);
+#endif
       v16i acc1[G];
 #pragma unroll
       for (int r = 0; r < OCB; ++r)
@@ -489,7 +524,7 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
       asm volatile("" : "+s"(rb), "+s"(nv1));
       using T = std::true_type;
       using F = std::false_type;
-      auto emit = [&](auto check_tag) {
+      auto emit = [&](auto check_tag, auto mode_tag) {
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
           const int pl = 8 * (e >> 2) + (e & 3);  // + 4h: pixel of register e; e + 1 is the next pixel
@@ -504,10 +539,45 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
             p0 = (tile_dst + (size_t)((unsigned)pl * rb)) + (size_t)lane_off;
             p1 = (tile_dst + (size_t)((unsigned)(pl + 1) * rb)) + (size_t)lane_off;
           }
-          emit_pair<DST, G, 2>(p0, p1, acc1, e, ia, fb, fc, relu1, a.rm1, w0, w1);
+          emit_pair<DST, G, decltype(mode_tag)::value>(p0, p1, acc1, e, ia, fb, fc, relu1, a.rm1, w0, w1);
         }
       };
-      if (nvalid == 32) emit(F{}); else emit(T{});
+      const int mode1 = g.mode1;
+      if (DST == DFX_U8 && nvalid == 32) {
+        // ---- full tile, u8: per value one v_fma_f32 (mode 3) or v_add_f32 + v_mul_f32 (mode 2) and one
+        //      v_cvt_pk_u8_f32 (RNE + [0, 255] saturation = ReLU + vcvtps2dq + vpmovusdb on the values the host
+        //      admits to these modes); per pixel one store with a scalar base, no address arithmetic ----
+        auto fast = [&](auto mode_tag) {
+          constexpr int MODE = decltype(mode_tag)::value;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            constexpr int dummy = 0; (void)dummy;
+            const int pl = 8 * (e >> 2) + (e & 3);  // + 4h (in lane_off): pixel of accumulator register e
+            unsigned pk = 0;
+#pragma unroll
+            for (int cc = 0; cc < G; ++cc) {
+              const float x = __int_as_float(acc1[cc][e]);
+              const float f = MODE == 3 ? __builtin_fmaf(x, fc[cc][0], fb[cc][0]) : __fmul_rn(__fadd_rn(x, fb[cc][0]), fc[cc][0]);
+              pk = __builtin_amdgcn_cvt_pk_u8_f32(f, cc, pk);
+            }
+            const unsigned off = (unsigned)pl * row_bytes;
+            const unsigned char *sb = tile_dst + (off & ~4095u);
+            switch (off & 4095u) {  // (compile-time after unrolling: pl and row_bytes are constants)
+#define RL_CASE(V) case V: store_dword_saddr_nt<V>(sb, lane_off, pk); break;
+              RL_CASE(0) RL_CASE(128) RL_CASE(256) RL_CASE(384) RL_CASE(512) RL_CASE(640) RL_CASE(768) RL_CASE(896)
+              RL_CASE(1024) RL_CASE(1152) RL_CASE(1280) RL_CASE(1408) RL_CASE(1536) RL_CASE(1664) RL_CASE(1792) RL_CASE(1920)
+              RL_CASE(2048) RL_CASE(2176) RL_CASE(2304) RL_CASE(2432) RL_CASE(2560) RL_CASE(2688) RL_CASE(2816) RL_CASE(2944)
+              RL_CASE(3072) RL_CASE(3200) RL_CASE(3328) RL_CASE(3456) RL_CASE(3584) RL_CASE(3712) RL_CASE(3840) RL_CASE(3968)
+#undef RL_CASE
+            }
+          }
+        };
+        if (mode1 == 3) fast(std::integral_constant<int, 3>{}); else fast(std::integral_constant<int, 2>{});
+      } else if (mode1 == 3) {
+        if (nvalid == 32) emit(F{}, std::integral_constant<int, 3>{}); else emit(T{}, std::integral_constant<int, 3>{});
+      } else {
+        if (nvalid == 32) emit(F{}, std::integral_constant<int, 2>{}); else emit(T{}, std::integral_constant<int, 2>{});
+      }
       DFX_STAMP(b2);
       RL_ADD(0, b1 - b0); RL_ADD(1, b2 - b1); RL_ADD(3, 1);  // wait for a mid slot, conv1 + requant 1 + store issue, tiles
     }
@@ -536,17 +606,14 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
   auto draw = [&]() { return __builtin_amdgcn_ds_append((lds_int *)(ctrl + CTL_NEXT)); };
   // mid-slot claims: an ordinary returning add by all 64 lanes (+64 per claim, lane 0's result = the old value).
   // ds_append takes its address from M0 and is only relied upon for the word at LDS address 0 (CTL_NEXT).
-  auto draw_m = [&]() {
-    return __hip_atomic_fetch_add(ctrl + RCTL_MHEAD, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  };
-  struct Look { int full, end; v4i info; };
+  int v64 = 64;  // (one VGPR for the whole loop)
+  asm volatile("" : "+v"(v64));
+  auto draw_m = [&]() { return lds_add_rtn_lane0(4 * RCTL_MHEAD, v64); };
+  struct Look { int end; v4i info; };  // info[3] = generations published into the slot (see RCTL_* above)
   auto look = [&](int sl, int par) {
     Look l;
-    l.full = __hip_atomic_load(ctrl + CTL_FULL + sl, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    l.info[0] = __hip_atomic_load(ctrl + CTL_INFO + 4 * sl + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    l.info[1] = __hip_atomic_load(ctrl + CTL_INFO + 4 * sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    l.info[2] = __hip_atomic_load(ctrl + CTL_INFO + 4 * sl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    l.info[3] = 0;
+    typedef __attribute__((address_space(3))) const volatile v4i lds_v4i;  // (LDS pointer: never a flat load)
+    l.info = *(lds_v4i *)(ctrl + CTL_INFO + 4 * sl);
     l.end = __hip_atomic_load(ctrl + CTL_END + par, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return l;
   };
@@ -567,9 +634,9 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
     bool have = false;
     v4i info = lk.info;
     for (int spin = 0; spin < MFMA_SPIN_LIMIT; ++spin) {
-      if (__builtin_amdgcn_readfirstlane(lk.full) >= gen + 1) { have = true; info = lk.info; break; }
+      if (__builtin_amdgcn_readfirstlane(lk.info[3]) >= gen + 1) { have = true; info = lk.info; break; }
       if (__builtin_amdgcn_readfirstlane(lk.end) <= k) break;
-      __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_s_sleep(4);
       lk = look(s, p);
     }
     const int k_cur = k, ti_cur = ti;
@@ -628,14 +695,18 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
       v16i acc0[OCB];
       {
         constexpr int NS = 9 * ICB;  // k-steps
-        constexpr int RD = DFX_RING;
+        constexpr int RD = RL_RING;
         v4i fbr[RD], fw[RD][OCB];
         auto fetch = [&](int st, int slot) {  // st, slot are compile-time after unrolling
           const int tap = st / ICB, c = st % ICB;
           fbr[slot] = *reinterpret_cast<const v4i *>(ins + (tap / 3) * lds_row + bb[tap % 3][c]);
 #pragma unroll
           for (int r = 0; r < OCB; ++r)
+#ifndef DFX_X_NOWLOAD
             fw[slot][r] = *reinterpret_cast<const v4i *>(w0s + ((r * 9 + tap) * ICB + c) * 1024 + lane16);
+#else  // timing experiment only (wrong results): what would conv0 cost without its weight-fragment reads?
+            fw[slot][r] = start[r].lo.lo.lo.xyxy + tap;
+#endif
         };
 #pragma unroll
         for (int st = 0; st < RD - 1; ++st) fetch(st, st);
@@ -650,27 +721,25 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
         }
       }
       DFX_STAMP(a2);
-      // every fragment of the tile has been consumed: count this claim off on its input slot
-      __hip_atomic_fetch_add(ctrl + CTL_DONE + s, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // all lanes: + 64
+      // every fragment of the tile has been consumed (the MFMAs that took the last ones have been issued): count
+      // this claim off on its input slot
+      lds_add_lane0(4 * (CTL_DONE + s), v64);
       next_claim();
       // ---- requant 0 ("fma" mode) -> A fragments of the 1x1 ----
       v4i mid[OCB];
       const int h4 = 4 * h;
-      if (g.s0_uniform) {
-        const v2f sc2 = {g.s0_value, g.s0_value};
-        const v2f cc2 = {-8388608.0f * g.s0_value, -8388608.0f * g.s0_value};
+      if (g.s0_uniform) {  // the op's single conv0 scale: a scalar operand, no per-channel reads
+        const float su = g.s0_value;
+        float cu = -8388608.0f * g.s0_value;
+        asm volatile("" : "+v"(cu));  // (one VGPR; v_fma_f32 takes one scalar operand)
 #pragma unroll
         for (int r = 0; r < OCB; ++r)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             unsigned pk = 0;
 #pragma unroll
-            for (int i = 0; i < 4; i += 2) {
-              v2f x = {__int_as_float(acc0[r][4 * q + i]), __int_as_float(acc0[r][4 * q + i + 1])};
-              x = __builtin_elementwise_fma(x, sc2, cc2);
-              pk = __builtin_amdgcn_cvt_pk_u8_f32(x[0], i, pk);
-              pk = __builtin_amdgcn_cvt_pk_u8_f32(x[1], i + 1, pk);
-            }
+            for (int i = 0; i < 4; ++i)  // plain v_fma_f32: the packed form does not overlap with MFMAs (conv_mfma.cuh)
+              pk = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(__int_as_float(acc0[r][4 * q + i]), su, cu), i, pk);
             mid[r][q] = (int)(pk ^ 0x80808080u);
           }
       } else {
@@ -682,37 +751,33 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
             const v4f cc = *reinterpret_cast<const v4f *>(fb0 + 32 * r + 8 * q + h4);
             unsigned pk = 0;
 #pragma unroll
-            for (int i = 0; i < 4; i += 2) {
-              v2f x = {__int_as_float(acc0[r][4 * q + i]), __int_as_float(acc0[r][4 * q + i + 1])};
-              x = __builtin_elementwise_fma(x, v2f{sc[i], sc[i + 1]}, v2f{cc[i], cc[i + 1]});
-              pk = __builtin_amdgcn_cvt_pk_u8_f32(x[0], i, pk);
-              pk = __builtin_amdgcn_cvt_pk_u8_f32(x[1], i + 1, pk);
-            }
+            for (int i = 0; i < 4; ++i)
+              pk = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(__int_as_float(acc0[r][4 * q + i]), sc[i], cc[i]), i, pk);
             mid[r][q] = (int)(pk ^ 0x80808080u);
           }
       }
       DFX_STAMP(a3);
       // ---- publish into the mid ring ----
-      const int m = __builtin_amdgcn_readfirstlane(m_ahead) >> 6;
+      const int m = lds_rtn_wait(m_ahead) >> 6;
       const int ms = m & (NM - 1), mgen = m >> LOG_NM;
       if (!w1_gone) {
         for (int spin = 0; spin < MFMA_SPIN_LIMIT && ctl_load(RCTL_W1DONE) < 64 * RL_B; ++spin) __builtin_amdgcn_s_sleep(1);
         w1_gone = true;
       }
-      for (int spin = 0; spin < MFMA_SPIN_LIMIT && ctl_load(RCTL_MFREE + ms) < 64 * NCG * mgen; ++spin) __builtin_amdgcn_s_sleep(1);
+      for (int spin = 0; spin < MFMA_SPIN_LIMIT && ctl_load(RCTL_MFREE + ms) < 64 * NCG * mgen; ++spin) __builtin_amdgcn_s_sleep(4);
       DFX_STAMP(a4);
       unsigned char *mslot = w1s + ms * (OCB * 1024);
 #pragma unroll
       for (int r = 0; r < OCB; ++r) *reinterpret_cast<v4i *>(mslot + r * 1024 + lane16) = mid[r];
-      ctrl[RCTL_MINFO + 4 * ms + 0] = obase;
-      ctrl[RCTL_MINFO + 4 * ms + 1] = nvalid;
+      typedef int v2i __attribute__((ext_vector_type(2)));
+      *reinterpret_cast<v2i *>(ctrl + RCTL_MINFO + 4 * ms) = v2i{obase, nvalid};
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // all lanes' writes first
       ctl_store(RCTL_MFULL + ms, mgen + 1);
       DFX_STAMP(a5);
       // address math + conv0, requant 0, wait for a free mid slot, write + publish, tiles
       RL_ADD(1, a2 - a1); RL_ADD(2, a3 - a2); RL_ADD(5, a4 - a3); RL_ADD(6, a5 - a4); RL_ADD(3, 1);
     } else {  // a claim beyond its unit's tiles: nothing to compute
-      __hip_atomic_fetch_add(ctrl + CTL_DONE + s, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      lds_add_lane0(4 * (CTL_DONE + s), v64);
       next_claim();
     }
   }

@@ -1324,6 +1324,18 @@ int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei, const void *bia0, con
       if (!fast_ok(c0[oc], b0[oc], s0[oc]) || !fma0_ok(c0[oc], b0[oc], s0[oc])) roles = false;
     if (roles) mode0 = 3;
     h->roles = roles;
+    // "fma" for stage 1 (role-specialised kernel only): (x + B) * C = fma(x, C, B * C) with one rounding when
+    // the addend B * C = (comp + bias - 2^23 - 0x22F983) * scale is exactly representable -- power-of-two scales
+    // and a few others; checked per channel in double (a 24-bit integer times a 24-bit mantissa is exact there)
+    if (roles) {
+      bool fma1 = true;
+      for (int o1 = 0; o1 < OC1 && fma1; ++o1) {
+        const double k = 128.0 * (c1[o1].P - c1[o1].N) + (double)b1[o1] - 8388608.0 - (double)0x22F983;
+        const double prod = k * (double)s1[o1];
+        fma1 = std::isfinite(prod) && (double)(float)prod == prod;
+      }
+      if (fma1) mode1 = 3;
+    }
     if (h->variant == DFX_VARIANT_MFMA_FUSED) {
       if (roles) snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_mfma_roles_kernel<%d,%d,%d,%d>", ICB, OCB, NCB, d.dst_dt);
       else snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_mfma_fused_kernel<%d,%d,%d,%d>", ICB, OCB, G, d.dst_dt);
@@ -1334,7 +1346,10 @@ int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei, const void *bia0, con
     auto inline_stage = [&](int mode, const Ch &c, float bias, float scale, float *A, float *B, float *C) {
       const int32_t comp = (int32_t)(128.0 * (c.P - c.N));
       put_i(A, comp - MAGIC1_BITS);  // acc bits + A = the reference's s32 accumulator
-      if (mode == 2) {
+      if (mode == 3) {  // fma(x, C, B): B = (comp + bias - 2^23 - 0x22F983) * scale (proven exact), C = scale * 2^26
+        *B = (float)(((double)comp + (double)bias - 8388608.0 - (double)0x22F983) * (double)scale);
+        *C = scale * 67108864.0f;
+      } else if (mode == 2) {
         *B = (float)((double)comp + (double)bias - 8388608.0 - (double)0x22F983) * 1.4901161193847656e-08f;  // * 2^-26, exact
         *C = scale * 67108864.0f;                                                                           // * 2^26, exact
       } else {
