@@ -67,12 +67,13 @@ constexpr int RL_WAVES = RL_C + MFMA_TEAMS;          // + 2 loaders
 constexpr int RL_THREADS = 64 * RL_WAVES;            // 768
 constexpr int RL_CTRL_BYTES = 512;                   // control block: the words of conv_mfma.cuh + the mid ring's
 constexpr int MAGIC3_BITS = 0x4B000000;              // 2^23: stage-0 accumulator start of the "fma" mode
+constexpr int RL_SPIN_LIMIT = 1 << 19;               // bound of the s_sleep(4) waits (~0.1 s): a protocol error ends the launch with
+                                                     // wrong output (the parity tests catch it) instead of hanging the GPU
 
 // control words (ints) behind those of conv_mfma.cuh (CTL_*, < 32)
-constexpr int RCTL_MHEAD = 32;   // 64 x mid slots claimed by A waves
 constexpr int RCTL_ADONE = 33;   // 64 x A waves that have left
-constexpr int RCTL_W1DONE = 34;  // 64 x B waves that hold their 1x1 fragments in registers
 constexpr int RCTL_MTAIL = 36;   // [4] per channel group: 64 x mid slots claimed by the group's B waves
+constexpr int RCTL_W1DONE = 34;  // 64 x B waves that hold their 1x1 fragments in registers
 constexpr int RCTL_MFULL = 40;   // [8] generations published into mid slot s
 constexpr int RCTL_MFREE = 48;   // [8] 64 x reads of mid slot s counted off (NCG per generation: one per channel group)
 constexpr int RCTL_MINFO = 64;   // [8][4] per mid slot: dst pixel index of the tile's first pixel, valid pixels
@@ -100,16 +101,14 @@ __device__ __forceinline__ void store_dword_saddr_nt(const void *sbase, unsigned
 __device__ __forceinline__ void lds_add_lane0(int addr, int val) {
   asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(addr), "v"(val) : "memory");
 }
-// returning form: the old value arrives in lane 0 of the result some hundred cycles later; lds_rtn_wait() before
-// its first use (hipcc does not count asm-issued LDS operations; its own s_waitcnt lgkmcnt(n) only ever wait
-// longer because of them: a wave's LDS operations complete in order)
-__device__ __forceinline__ int lds_add_rtn_lane0(int addr, int val) {
+// Returning form, SYNCHRONOUS: the wait for the result is inside the asm statement.  (An asm-issued ds_add_rtn
+// delivers its result asynchronously into a register hipcc believes written already; with the wait in a second
+// statement a copy hipcc inserted in between -- for a loop-carried value -- read stale data: found as randomly
+// skipped tiles.)  Place it where the wave has to wait anyway, e.g. behind freshly issued MFMAs.
+__device__ __forceinline__ int lds_add_rtn_lane0_sync(int addr, int val) {
   int r;
-  asm volatile("s_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %1, %2\n\ts_mov_b64 exec, -1" : "=v"(r) : "v"(addr), "v"(val) : "memory");
-  return r;
-}
-__device__ __forceinline__ int lds_rtn_wait(int r) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r)::"memory");
+  asm volatile("s_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %1, %2\n\ts_mov_b64 exec, -1\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(r) : "v"(addr), "v"(val) : "memory");
   return __builtin_amdgcn_readfirstlane(r);
 }
 
@@ -401,6 +400,10 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
 #pragma unroll
         for (int i = 0; i < NTL; ++i) tv[i] = load_granule(src_n, y0, x0, min(tctid + i * TT, g.tile_chunks - 1));
       }
+#ifdef DFX_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      RL_ADD(7, dfx_stamp() - t_entry);  // entry -> staged global loads have arrived
+#endif
 #pragma unroll
       for (int i = 0; i < NW; ++i)
         if (ctid + i * NT < total) d[ctid + i * NT] = wv[i];
@@ -436,7 +439,9 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
       ctrl[ctid] = v;
     }
   }
+  RL_ADD(8, dfx_stamp() - t_entry);  // entry -> own staging done (LDS written)
   __syncthreads();
+  RL_ADD(9, dfx_stamp() - t_entry);  // entry -> past the barrier
 
   typedef __attribute__((address_space(3))) int lds_int;
   const bool relu1 = a.relu1 || DST == DFX_U8;
@@ -444,11 +449,12 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
   if (wave >= RL_A) {
     // =========================== B wave: conv1 + requant 1 + stores ===========================
     // A B wave serves ONE group of G = 4 column blocks (128 output channels) of every tile, wave j group
-    // j % NCG: its G x OCB weight fragments and its lane's requant constants are loaded once and stay in
-    // registers; a mid slot is read by one wave of every group and free when all NCG have counted it off.
+    // j % NCG: its G x OCB weight fragments and its lane's requant constants (2 floats per channel) are loaded
+    // once and stay in registers; a mid slot is read by one wave of every group and free when all NCG have counted
+    // it off.  (Whole tiles per wave -- all NCB x OCB fragments resident -- would save the per-visit control
+    // instructions of NCG - 1 waves, but needs > 168 VGPRs at the headline shape: hipcc spilled 35.)
     const int cg = (wave - RL_A) % NCG;
-    const int *ia1 = reinterpret_cast<const int *>(cst + 3 * OC);
-    const v2f *pb1 = reinterpret_cast<const v2f *>(cst + 3 * OC + OC1), *pc1 = reinterpret_cast<const v2f *>(cst + 3 * OC + 3 * OC1);
+    const float *pb1 = cst + 3 * OC + OC1, *pc1 = cst + 3 * OC + 3 * OC1;  // {k, k} pairs (conv_mfma.cuh): [2 * channel]
     constexpr unsigned row_bytes = OC1;  // dst bytes per pixel
     const int l31 = lane & 31, h4 = 4 * (lane >> 5);
     const int chb = 32 * G * cg + G * l31;  // this lane's first channel
@@ -458,32 +464,28 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
 #pragma unroll
       for (int r = 0; r < OCB; ++r)
         w1r[cc][r] = *reinterpret_cast<const v4i *>(w1s + ((cg * G + cc) * OCB + r) * 1024 + lane * 16);
-    int ia[G];
-    v2f fb[G], fc[G];
+    float fbk[G], fck[G];
 #pragma unroll
     for (int cc = 0; cc < G; ++cc) {
-      ia[cc] = ia1[chb + cc];
-      fb[cc] = pb1[chb + cc];
-      fc[cc] = pc1[chb + cc];
+      fbk[cc] = pb1[2 * (chb + cc)];
+      fck[cc] = pc1[2 * (chb + cc)];
     }
     // (LDS executes a wave's DS instructions in order: the add below follows the reads above)
     __hip_atomic_fetch_add(ctrl + RCTL_W1DONE, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // all lanes: + 64
     const unsigned lane_off = (unsigned)h4 * row_bytes + (unsigned)chb;
-    const unsigned ch_off = (unsigned)chb;
     int v64 = 64;  // (one VGPR for the whole loop)
     asm volatile("" : "+v"(v64));
-    // (an ordinary returning add, not ds_append: see draw_m in the A wave)
-    auto draw_b = [&]() { return lds_add_rtn_lane0(4 * (RCTL_MTAIL + cg), v64); };
-    int b_claim = draw_b();
+    // Mid slot b holds the CU's b-th tile claim (A waves publish every claim, empty ones too); the waves of a
+    // group claim them from the group's counter.
+    int b = lds_add_rtn_lane0_sync(4 * (RCTL_MTAIL + cg), v64) >> 6;
     RL_ADD(4, dfx_stamp() - t_entry);  // entry -> tile loop
     for (;;) {
       DFX_STAMP(b0);
-      const int b = lds_rtn_wait(b_claim) >> 6;
       const int bs = b & (NM - 1), bgen = b >> LOG_NM;
       bool have = ctl_load(RCTL_MFULL + bs) >= bgen + 1;
-      for (int spin = 0; !have && spin < MFMA_SPIN_LIMIT; ++spin) {
-        // every A wave has left (each published all of its tiles first): MHEAD is final
-        if (ctl_load(RCTL_ADONE) >= 64 * RL_A && (ctl_load(RCTL_MHEAD) >> 6) <= b) {
+      for (int spin = 0; !have && spin < RL_SPIN_LIMIT; ++spin) {
+        // every A wave has left, and each published all of its claims first: nothing more will come
+        if (ctl_load(RCTL_ADONE) >= 64 * RL_A) {
           have = ctl_load(RCTL_MFULL + bs) >= bgen + 1;
           break;
         }
@@ -504,79 +506,81 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
       // this wave is done with the slot once its reads have returned: LDS serves a wave's operations in order, so
       // the add (and the next claim behind it) cannot overtake them
       lds_add_lane0(4 * (RCTL_MFREE + bs), v64);
-      b_claim = draw_b();  // the next claim travels while this tile is computed
       const int obase_i = __builtin_amdgcn_readfirstlane(minfo.x);
       const int nvalid = __builtin_amdgcn_readfirstlane(minfo.y);
+      if (nvalid == 0) {  // an empty claim (beyond its unit's tiles, or a unit that does not exist)
+        b = lds_add_rtn_lane0_sync(4 * (RCTL_MTAIL + cg), v64) >> 6;
+        continue;
+      }
 #ifndef DFX_X_LOCALSTORE
       unsigned char *tile_dst = reinterpret_cast<unsigned char *>(a.dst) + (size_t)obase_i * row_bytes;
 #else  // timing experiment only: every tile of a workgroup is written to the same 8 KB (stays in L2, no HBM writes)
       unsigned char *tile_dst = reinterpret_cast<unsigned char *>(a.dst) + (size_t)blockIdx.x * 32 * row_bytes + (obase_i & 0);
 #endif
-      v16i acc1[G];
-#pragma unroll
-      for (int r = 0; r < OCB; ++r)
-#pragma unroll
-        for (int cc = 0; cc < G; ++cc)
-          acc1[cc] = r == 0 ? mfma_i8_from_magic(mid[0], w1r[cc][0]) : mfma_i8(mid[r], w1r[cc][r], acc1[cc]);
-      if (OCB == 1) asm volatile("s_nop 7\n\ts_nop 4" ::: "memory");  // (asm MFMA results: see conv_mfma.cuh)
-      unsigned rb = row_bytes;
-      int nv1 = nvalid - 1;
-      asm volatile("" : "+s"(rb), "+s"(nv1));
-      using T = std::true_type;
-      using F = std::false_type;
-      auto emit = [&](auto check_tag, auto mode_tag) {
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-          const int pl = 8 * (e >> 2) + (e & 3);  // + 4h: pixel of register e; e + 1 is the next pixel
-          unsigned char *p0, *p1;
-          bool w0 = true, w1 = true;
-          if (decltype(check_tag)::value) {  // partial tile: pixels beyond its end are not written
-            w0 = pl + h4 <= nv1;
-            w1 = pl + 1 + h4 <= nv1;
-            p0 = tile_dst + ((unsigned)min(pl + h4, nv1) * rb + ch_off);
-            p1 = tile_dst + ((unsigned)min(pl + 1 + h4, nv1) * rb + ch_off);
-          } else {  // scalar pixel base + one per-lane offset
-            p0 = (tile_dst + (size_t)((unsigned)pl * rb)) + (size_t)lane_off;
-            p1 = (tile_dst + (size_t)((unsigned)(pl + 1) * rb)) + (size_t)lane_off;
-          }
-          emit_pair<DST, G, decltype(mode_tag)::value>(p0, p1, acc1, e, ia, fb, fc, relu1, a.rm1, w0, w1);
-        }
-      };
       const int mode1 = g.mode1;
-      if (DST == DFX_U8 && nvalid == 32) {
-        // ---- full tile, u8: per value one v_fma_f32 (mode 3) or v_add_f32 + v_mul_f32 (mode 2) and one
-        //      v_cvt_pk_u8_f32 (RNE + [0, 255] saturation = ReLU + vcvtps2dq + vpmovusdb on the values the host
-        //      admits to these modes); per pixel one store with a scalar base, no address arithmetic ----
-        auto fast = [&](auto mode_tag) {
-          constexpr int MODE = decltype(mode_tag)::value;
+      {
+        v16i acc1[G];
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            constexpr int dummy = 0; (void)dummy;
-            const int pl = 8 * (e >> 2) + (e & 3);  // + 4h (in lane_off): pixel of accumulator register e
-            unsigned pk = 0;
+        for (int r = 0; r < OCB; ++r)
 #pragma unroll
-            for (int cc = 0; cc < G; ++cc) {
-              const float x = __int_as_float(acc1[cc][e]);
-              const float f = MODE == 3 ? __builtin_fmaf(x, fc[cc][0], fb[cc][0]) : __fmul_rn(__fadd_rn(x, fb[cc][0]), fc[cc][0]);
-              pk = __builtin_amdgcn_cvt_pk_u8_f32(f, cc, pk);
-            }
-            const unsigned off = (unsigned)pl * row_bytes;
-            const unsigned char *sb = tile_dst + (off & ~4095u);
-            switch (off & 4095u) {  // (compile-time after unrolling: pl and row_bytes are constants)
+          for (int cc = 0; cc < G; ++cc)
+            acc1[cc] = r == 0 ? mfma_i8_from_magic(mid[0], w1r[cc][0]) : mfma_i8(mid[r], w1r[cc][r], acc1[cc]);
+        if (OCB == 1) asm volatile("s_nop 7\n\ts_nop 4" ::: "memory");  // (asm MFMA results: see conv_mfma.cuh)
+        // the next claim, behind the MFMAs just issued: its LDS round trip passes while they execute
+        b = lds_add_rtn_lane0_sync(4 * (RCTL_MTAIL + cg), v64) >> 6;
+        if (DST == DFX_U8 && nvalid == 32) {
+          // ---- full tile, u8: per value one v_fma_f32 (mode 3) or v_add_f32 + v_mul_f32 (mode 2) and one
+          //      v_cvt_pk_u8_f32 (RNE + [0, 255] saturation = ReLU + vcvtps2dq + vpmovusdb on the values the host
+          //      admits to these modes); per pixel one store with a scalar base, no address arithmetic ----
+          auto fast = [&](auto mode_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int pl = 8 * (e >> 2) + (e & 3);  // + 4h (in lane_off): pixel of accumulator register e
+              unsigned pk = 0;
+#pragma unroll
+              for (int cc = 0; cc < G; ++cc) {
+                const float x = __int_as_float(acc1[cc][e]);
+                const float f = MODE == 3 ? __builtin_fmaf(x, fck[cc], fbk[cc]) : __fmul_rn(__fadd_rn(x, fbk[cc]), fck[cc]);
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(f, cc, pk);
+              }
+              const unsigned off = (unsigned)pl * row_bytes;
+              const unsigned char *sb = tile_dst + (off & ~4095u);
+              switch (off & 4095u) {  // (compile-time after unrolling: pl and row_bytes are constants)
 #define RL_CASE(V) case V: store_dword_saddr_nt<V>(sb, lane_off, pk); break;
-              RL_CASE(0) RL_CASE(128) RL_CASE(256) RL_CASE(384) RL_CASE(512) RL_CASE(640) RL_CASE(768) RL_CASE(896)
-              RL_CASE(1024) RL_CASE(1152) RL_CASE(1280) RL_CASE(1408) RL_CASE(1536) RL_CASE(1664) RL_CASE(1792) RL_CASE(1920)
-              RL_CASE(2048) RL_CASE(2176) RL_CASE(2304) RL_CASE(2432) RL_CASE(2560) RL_CASE(2688) RL_CASE(2816) RL_CASE(2944)
-              RL_CASE(3072) RL_CASE(3200) RL_CASE(3328) RL_CASE(3456) RL_CASE(3584) RL_CASE(3712) RL_CASE(3840) RL_CASE(3968)
+                RL_CASE(0) RL_CASE(128) RL_CASE(256) RL_CASE(384) RL_CASE(512) RL_CASE(640) RL_CASE(768) RL_CASE(896)
+                RL_CASE(1024) RL_CASE(1152) RL_CASE(1280) RL_CASE(1408) RL_CASE(1536) RL_CASE(1664) RL_CASE(1792) RL_CASE(1920)
+                RL_CASE(2048) RL_CASE(2176) RL_CASE(2304) RL_CASE(2432) RL_CASE(2560) RL_CASE(2688) RL_CASE(2816) RL_CASE(2944)
+                RL_CASE(3072) RL_CASE(3200) RL_CASE(3328) RL_CASE(3456) RL_CASE(3584) RL_CASE(3712) RL_CASE(3840) RL_CASE(3968)
 #undef RL_CASE
+              }
             }
+          };
+          if (mode1 == 3) fast(std::integral_constant<int, 3>{}); else fast(std::integral_constant<int, 2>{});
+        } else {
+          // partial tiles and s8 output: conv_mfma.cuh's pixel-pair emitter (predicated stores beyond the tile's end)
+          int ia[G];
+          v2f fb[G], fc[G];
+#pragma unroll
+          for (int cc = 0; cc < G; ++cc) {
+            ia[cc] = 0;
+            fb[cc] = v2f{fbk[cc], fbk[cc]};
+            fc[cc] = v2f{fck[cc], fck[cc]};
           }
-        };
-        if (mode1 == 3) fast(std::integral_constant<int, 3>{}); else fast(std::integral_constant<int, 2>{});
-      } else if (mode1 == 3) {
-        if (nvalid == 32) emit(F{}, std::integral_constant<int, 3>{}); else emit(T{}, std::integral_constant<int, 3>{});
-      } else {
-        if (nvalid == 32) emit(F{}, std::integral_constant<int, 2>{}); else emit(T{}, std::integral_constant<int, 2>{});
+          const int nv1 = nvalid - 1;
+          const unsigned ch_off = (unsigned)chb;
+          auto emit = [&](auto mode_tag) {
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+              const int pl = 8 * (e >> 2) + (e & 3);  // + 4h: pixel of register e; e + 1 is the next pixel
+              const bool w0 = pl + h4 <= nv1, w1 = pl + 1 + h4 <= nv1;
+              unsigned char *p0 = tile_dst + ((unsigned)min(pl + h4, nv1) * row_bytes + ch_off);
+              unsigned char *p1 = tile_dst + ((unsigned)min(pl + 1 + h4, nv1) * row_bytes + ch_off);
+              emit_pair<DST, G, decltype(mode_tag)::value>(p0, p1, acc1, e, ia, fb, fc, relu1, a.rm1, w0, w1);
+            }
+          };
+          if (mode1 == 3) emit(std::integral_constant<int, 3>{}); else emit(std::integral_constant<int, 2>{});
+        }
       }
       DFX_STAMP(b2);
       RL_ADD(0, b1 - b0); RL_ADD(1, b2 - b1); RL_ADD(3, 1);  // wait for a mid slot, conv1 + requant 1 + store issue, tiles
@@ -608,7 +612,6 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
   // ds_append takes its address from M0 and is only relied upon for the word at LDS address 0 (CTL_NEXT).
   int v64 = 64;  // (one VGPR for the whole loop)
   asm volatile("" : "+v"(v64));
-  auto draw_m = [&]() { return lds_add_rtn_lane0(4 * RCTL_MHEAD, v64); };
   struct Look { int end; v4i info; };  // info[3] = generations published into the slot (see RCTL_* above)
   auto look = [&](int sl, int par) {
     Look l;
@@ -633,7 +636,7 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
     const int s = k & (MFMA_NB - 1), gen = k >> 2, p = k & 1;
     bool have = false;
     v4i info = lk.info;
-    for (int spin = 0; spin < MFMA_SPIN_LIMIT; ++spin) {
+    for (int spin = 0; spin < RL_SPIN_LIMIT; ++spin) {
       if (__builtin_amdgcn_readfirstlane(lk.info[3]) >= gen + 1) { have = true; info = lk.info; break; }
       if (__builtin_amdgcn_readfirstlane(lk.end) <= k) break;
       __builtin_amdgcn_s_sleep(4);
@@ -645,8 +648,20 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
       split(t, k, ti);
       lk = look(k & (MFMA_NB - 1), k & 1);
     };
+    const int t_cur = t;
+    // Mid slot of claim t: t % NM, generation t / NM -- every claim that is not the wave's last publishes one, if
+    // only an empty record (valid pixels = 0), so that the B waves can walk the slots in claim order.
+    auto publish_empty = [&]() {
+      const int ms = t_cur & (NM - 1), mgen = t_cur >> LOG_NM;
+      for (int spin = 0; spin < RL_SPIN_LIMIT && ctl_load(RCTL_MFREE + ms) < 64 * NCG * mgen; ++spin) __builtin_amdgcn_s_sleep(4);
+      typedef int v2i __attribute__((ext_vector_type(2)));
+      *reinterpret_cast<v2i *>(ctrl + RCTL_MINFO + 4 * ms) = v2i{0, 0};
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      ctl_store(RCTL_MFULL + ms, mgen + 1);
+    };
     if (!have) {  // stream p has no k-th unit; done when the other stream has none for k + 1 either
       if (ctl_load(CTL_END + (p ^ 1)) <= k_cur + 1) break;
+      publish_empty();
       c_ahead = draw();
       next_claim();
       continue;
@@ -662,7 +677,6 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
     RL_ADD(0, a1 - a0);  // wait for the tile's unit
     c_ahead = draw();  // the next tile's claim travels during conv0
     if (ti_cur < ntiles) {
-      const int m_ahead = draw_m();  // this tile's mid slot, needed after requant 0
       const int l31 = lane & 31, h = lane >> 5;
       int ty, tx, nvalid, obase;
       if (g.linear) {
@@ -699,13 +713,19 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
         v4i fbr[RD], fw[RD][OCB];
         auto fetch = [&](int st, int slot) {  // st, slot are compile-time after unrolling
           const int tap = st / ICB, c = st % ICB;
+          // issue order = reverse of the use order (the step's first MFMA takes fw[0] and fbr): one s_waitcnt before
+          // the first MFMA then covers the whole step (a wave's LDS reads return in order)
+#ifdef DFX_X_OLDFETCH
           fbr[slot] = *reinterpret_cast<const v4i *>(ins + (tap / 3) * lds_row + bb[tap % 3][c]);
 #pragma unroll
           for (int r = 0; r < OCB; ++r)
-#ifndef DFX_X_NOWLOAD
             fw[slot][r] = *reinterpret_cast<const v4i *>(w0s + ((r * 9 + tap) * ICB + c) * 1024 + lane16);
-#else  // timing experiment only (wrong results): what would conv0 cost without its weight-fragment reads?
-            fw[slot][r] = start[r].lo.lo.lo.xyxy + tap;
+#else
+#pragma unroll
+          for (int r = OCB - 1; r >= 1; --r)
+            fw[slot][r] = *reinterpret_cast<const v4i *>(w0s + ((r * 9 + tap) * ICB + c) * 1024 + lane16);
+          fbr[slot] = *reinterpret_cast<const v4i *>(ins + (tap / 3) * lds_row + bb[tap % 3][c]);
+          fw[slot][0] = *reinterpret_cast<const v4i *>(w0s + ((0 * 9 + tap) * ICB + c) * 1024 + lane16);
 #endif
         };
 #pragma unroll
@@ -758,13 +778,12 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
       }
       DFX_STAMP(a3);
       // ---- publish into the mid ring ----
-      const int m = lds_rtn_wait(m_ahead) >> 6;
-      const int ms = m & (NM - 1), mgen = m >> LOG_NM;
+      const int ms = t_cur & (NM - 1), mgen = t_cur >> LOG_NM;
       if (!w1_gone) {
-        for (int spin = 0; spin < MFMA_SPIN_LIMIT && ctl_load(RCTL_W1DONE) < 64 * RL_B; ++spin) __builtin_amdgcn_s_sleep(1);
+        for (int spin = 0; spin < RL_SPIN_LIMIT && ctl_load(RCTL_W1DONE) < 64 * RL_B; ++spin) __builtin_amdgcn_s_sleep(1);
         w1_gone = true;
       }
-      for (int spin = 0; spin < MFMA_SPIN_LIMIT && ctl_load(RCTL_MFREE + ms) < 64 * NCG * mgen; ++spin) __builtin_amdgcn_s_sleep(4);
+      for (int spin = 0; spin < RL_SPIN_LIMIT && ctl_load(RCTL_MFREE + ms) < 64 * NCG * mgen; ++spin) __builtin_amdgcn_s_sleep(4);
       DFX_STAMP(a4);
       unsigned char *mslot = w1s + ms * (OCB * 1024);
 #pragma unroll
@@ -779,6 +798,7 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
     } else {  // a claim beyond its unit's tiles: nothing to compute
       lds_add_lane0(4 * (CTL_DONE + s), v64);
       next_claim();
+      publish_empty();
     }
   }
   __hip_atomic_fetch_add(ctrl + RCTL_ADONE, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // all lanes: + 64

@@ -55,6 +55,9 @@ for r, name, cols in ((0, "A (conv0 + requant 0)", ["wait for the tile's unit", 
             continue
         if c == "entry -> loop":
             print("   %-34s %8.0f cycles" % (c, w[:, k].mean()))
+            if r != 2:
+                print("   start-up: global loads arrived %6.0f, own LDS writes done %6.0f, past the barrier %6.0f (cycles after entry)" % (
+                    w[:, 7].mean(), w[:, 8].mean(), w[:, 9].mean()))
         else:
             print("   %-34s %8.0f cycles per %s   (%.1f%% of the wave's lifetime)" % (
                 c, (w[:, k] / n).mean(), "unit" if r == 2 else "tile", 100 * (w[:, k] / (w[:, 13] - w[:, 12])).mean()))
