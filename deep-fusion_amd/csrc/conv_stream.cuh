@@ -456,12 +456,8 @@ __global__ __launch_bounds__(ST_THREADS, 2) void conv_stream_kernel(ConvArgs a, 
             unsigned pk = 0;
             if (fast) {  // bias slot = comp + bias (exact); ReLU + RNE + saturation in v_cvt_pk_u8_f32
 #pragma unroll
-              for (int i = 0; i < 4; i += 2) {
-                v2f x = {__int2float_rn(acc[pb][r][4 * q + i]), __int2float_rn(acc[pb][r][4 * q + i + 1])};
-                x = (x + v2f{bs[i], bs[i + 1]}) * v2f{sc[i], sc[i + 1]};
-                pk = __builtin_amdgcn_cvt_pk_u8_f32(x[0], i, pk);
-                pk = __builtin_amdgcn_cvt_pk_u8_f32(x[1], i + 1, pk);
-              }
+              for (int i = 0; i < 4; ++i)  // plain v_add_f32 / v_mul_f32: the packed forms do not overlap with MFMAs (conv_mfma.cuh)
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(__fmul_rn(__fadd_rn(__int2float_rn(acc[pb][r][4 * q + i]), bs[i]), sc[i]), i, pk);
             } else {
               const v4i cp = *reinterpret_cast<const v4i *>(comp0 + ch);
 #pragma unroll
