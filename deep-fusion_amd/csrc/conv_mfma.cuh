@@ -939,7 +939,6 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
   DFX_TRACE_AT(2, 0, 0);
   DFX_STAMP(t_staged);  // (diagnostic builds: the stamp waits for this wave's LDS writes)
   __syncthreads();
-  const int l31 = lane & 31, h = lane >> 5;
   // constants in LDS: [A0 | B0 | C0] per conv0 channel, [A1 | B1 | C1] per 1x1 channel
   const int *ia0 = reinterpret_cast<const int *>(cst);
   const float *fb0 = cst + OC, *fc0 = cst + 2 * OC;                    // fused: scalars per conv0 channel

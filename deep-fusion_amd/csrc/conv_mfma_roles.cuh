@@ -60,8 +60,14 @@ namespace dfx {
 #ifndef RL_RING
 #define RL_RING 5  // conv0 fragment prefetch depth of an A wave (k-steps in flight)
 #endif
-constexpr int RL_A = 4;                              // conv0 waves
-constexpr int RL_B = 6;                              // conv1 + store waves
+#ifndef RL_NA
+#define RL_NA 6
+#endif
+#ifndef RL_NB
+#define RL_NB 8
+#endif
+constexpr int RL_A = RL_NA;                          // conv0 waves
+constexpr int RL_B = RL_NB;                          // conv1 + store waves
 constexpr int RL_C = RL_A + RL_B;                    // waves that stage the weights
 constexpr int RL_WAVES = RL_C + MFMA_TEAMS;          // + 2 loaders
 constexpr int RL_THREADS = 64 * RL_WAVES;            // 768
@@ -135,7 +141,7 @@ __device__ __forceinline__ int lds_add_rtn_lane0_sync(int addr, int val) {
 #endif
 
 template <int ICB, int OCB, int NCB, int DST>
-__global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs a, MfmaGeom g) {
+__global__ __launch_bounds__(RL_THREADS, (RL_WAVES + 3) / 4) void conv_mfma_roles_kernel(ConvArgs a, MfmaGeom g) {
   constexpr int IC = 32 * ICB, OC = 32 * OCB, CP = IC / 16, G = 4, NCG = NCB / G, OC1 = 32 * NCB;
   constexpr int NM = NCB >= 8 ? 8 : 4, LOG_NM = NCB >= 8 ? 3 : 2;  // mid slots (OCB KB each) inside the W1 area
   static_assert(DST == DFX_U8 || DST == DFX_S8, "1-byte outputs");
@@ -303,15 +309,10 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
       }
     };
     int j0 = coop0 ? 1 : 0;
-    if (coop1 && T + tg < g.total_units) {
-      const int u1 = T + tg;
-      unsigned char *ins1 = tiles + (size_t)(2 + team) * g.tile_stride;
-      DFX_PREFETCH(u1);
-      write_tile(ins1);
-      write_rest(ins1, u1);
-      j0 = 2;
-    }
+    if (coop1 && T + tg < g.total_units) j0 = 2;  // (its second unit is staged by the compute waves too, see there)
+    RL_ADD(8, dfx_stamp() - t_entry);  // entry -> second unit staged (reaches the barrier)
     if (coop0) __syncthreads();
+    RL_ADD(9, dfx_stamp() - t_entry);  // entry -> past the barrier
     const bool lazy = use_queue && g.lazy_queue;
     int cur = lazy ? 0 : __builtin_amdgcn_readfirstlane(unit_at(j0));
     int nxt_v = lazy ? 0 : unit_at(j0 + 1);
@@ -373,7 +374,6 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
 
   // =========================== A and B waves: stage weights, constants, first tiles ===========================
   {
-    constexpr int NT = RL_C * 64;        // staging threads
     constexpr int CWT = RL_C / 2;        // waves that stage one first tile
     constexpr int TT = CWT * 64;
     const int steam = wave / CWT, ctid = wave * 64 + lane, tctid = (wave % CWT) * 64 + lane;
@@ -386,36 +386,59 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
     const uint8_t *src_n = a.src;
     int y0 = 0, x0 = 0;
     if (tile0) unit_origin(unit0, src_n, y0, x0);
-    // ONE memory round trip: every global load of the weights, the constants and this thread's share of the first
-    // tile is issued before the first LDS write (two dependent passes cost a second ~2 us trip through a cold L2
-    // with all 256 workgroups asking at once).  NW chunks of weights per thread cover 64 KB; more than that (no
-    // supported shape) would take further passes.
-    constexpr int NW = 7, NTL = 5;  // 16-byte chunks per thread: weights + constants, first tile
+    // ONE memory round trip, and no VGPR / ds_write detour for the weights: the packed weights + constants go
+    // global -> LDS by LDS-DMA (global_load_lds_dwordx4: a wave moves 1 KB per instruction, lane i's 16 bytes land
+    // at the wave-uniform LDS base + 16 i; exec-masked lanes move nothing), issued before this thread's share of
+    // the first tile is loaded (that one needs the xor 0x80, so it travels through registers).  Through ds_write
+    // the 56 KB cost every staging wave ~1.5 k cycles of LDS store issue (stamps: loads arrived 3.5 k cycles
+    // after entry, LDS writes done 5.0 k).
     {
-      const int last = total - 1;
-      v4i wv[NW], tv[NTL];
-#pragma unroll
-      for (int i = 0; i < NW; ++i) wv[i] = s[min(ctid + i * NT, last)];
+      typedef __attribute__((address_space(3))) void lds_void;
+      typedef __attribute__((address_space(1))) const void global_void;
+      const int nblk = (total + 63) >> 6;  // 1 KB blocks
+      for (int j = wave; j < nblk; j += RL_C)
+        if (64 * j + lane < total)
+          __builtin_amdgcn_global_load_lds((global_void *)(s + 64 * j + lane), (lds_void *)(d + 64 * j), 16, 0, 0);
+      // The first TWO units of stream `steam` (both static: coop0 / coop1): all their global loads are issued
+      // before the first LDS write.  (Until round 3 the loader staged its second unit itself before the barrier:
+      // its table set-up put those loads ~3 k cycles behind everybody else's and the whole workgroup waited at the
+      // barrier for them -- stamps: compute waves there after 4.6-5.9 k cycles, loaders after 6.9 k.)
+      constexpr int NTL = 4;  // 16-byte chunks per thread and unit held in registers at once
+      const int unit1 = (int)gridDim.x * MFMA_TEAMS + unit0;
+      const bool tile1 = coop1 && unit1 < g.total_units;
+      unsigned char *slot1 = tiles + (size_t)(2 + steam) * g.tile_stride;
+      const uint8_t *src_n1 = a.src;
+      int y1 = 0, x1 = 0;
+      if (tile1) unit_origin(unit1, src_n1, y1, x1);
+      v4i tv[NTL], tw[NTL];
       if (tile0) {
 #pragma unroll
         for (int i = 0; i < NTL; ++i) tv[i] = load_granule(src_n, y0, x0, min(tctid + i * TT, g.tile_chunks - 1));
       }
-#ifdef DFX_STAMPS
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      RL_ADD(7, dfx_stamp() - t_entry);  // entry -> staged global loads have arrived
-#endif
+      if (tile1) {
 #pragma unroll
-      for (int i = 0; i < NW; ++i)
-        if (ctid + i * NT < total) d[ctid + i * NT] = wv[i];
+        for (int i = 0; i < NTL; ++i) tw[i] = load_granule(src_n1, y1, x1, min(tctid + i * TT, g.tile_chunks - 1));
+      }
       if (tile0) {
 #pragma unroll
         for (int i = 0; i < NTL; ++i)
           if (tctid + i * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (tctid + i * TT)) = tv[i];
       }
-      for (int q = ctid + NW * NT; q < total; q += NT) d[q] = s[q];  // (larger weight sets: further passes)
+      if (tile1) {
+#pragma unroll
+        for (int i = 0; i < NTL; ++i)
+          if (tctid + i * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot1 + 16 * (tctid + i * TT)) = tw[i];
+      }
       if (tile0)
         for (int q = tctid + NTL * TT; q < g.tile_chunks; q += TT)
           *reinterpret_cast<v4i *>(slot + 16 * q) = load_granule(src_n, y0, x0, q);
+      if (tile1)
+        for (int q = tctid + NTL * TT; q < g.tile_chunks; q += TT)
+          *reinterpret_cast<v4i *>(slot1 + 16 * q) = load_granule(src_n1, y1, x1, q);
+#ifdef DFX_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      RL_ADD(7, dfx_stamp() - t_entry);  // entry -> staged global loads have arrived
+#endif
     }
     if (ctid < RL_CTRL_BYTES / 4) {  // control block (see conv_mfma.cuh); the mid ring's words start at zero
       int v = 0;
@@ -439,6 +462,7 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
       ctrl[ctid] = v;
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA transfers have landed
   RL_ADD(8, dfx_stamp() - t_entry);  // entry -> own staging done (LDS written)
   __syncthreads();
   RL_ADD(9, dfx_stamp() - t_entry);  // entry -> past the barrier
@@ -528,12 +552,14 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
         if (OCB == 1) asm volatile("s_nop 7\n\ts_nop 4" ::: "memory");  // (asm MFMA results: see conv_mfma.cuh)
         // the next claim, behind the MFMAs just issued: its LDS round trip passes while they execute
         b = lds_add_rtn_lane0_sync(4 * (RCTL_MTAIL + cg), v64) >> 6;
-        if (DST == DFX_U8 && nvalid == 32) {
-          // ---- full tile, u8: per value one v_fma_f32 (mode 3) or v_add_f32 + v_mul_f32 (mode 2) and one
-          //      v_cvt_pk_u8_f32 (RNE + [0, 255] saturation = ReLU + vcvtps2dq + vpmovusdb on the values the host
-          //      admits to these modes); per pixel one store with a scalar base, no address arithmetic ----
-          auto fast = [&](auto mode_tag) {
+        if (DST == DFX_U8) {
+          // ---- u8: per value one v_fma_f32 (mode 3) or v_add_f32 + v_mul_f32 (mode 2) and one v_cvt_pk_u8_f32
+          //      (RNE + [0, 255] saturation = ReLU + vcvtps2dq + vpmovusdb on the values the host admits to these
+          //      modes); per pixel one store with a scalar base, no address arithmetic.  Partial tiles (CHECK):
+          //      the stores of pixels beyond the tile's end are predicated off ----
+          auto fast = [&](auto mode_tag, auto check_tag) {
             constexpr int MODE = decltype(mode_tag)::value;
+            constexpr bool CHECK = decltype(check_tag)::value;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
               const int pl = 8 * (e >> 2) + (e & 3);  // + 4h (in lane_off): pixel of accumulator register e
@@ -546,19 +572,27 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
               }
               const unsigned off = (unsigned)pl * row_bytes;
               const unsigned char *sb = tile_dst + (off & ~4095u);
-              switch (off & 4095u) {  // (compile-time after unrolling: pl and row_bytes are constants)
+              if (!CHECK || pl + h4 < nvalid) {
+                switch (off & 4095u) {  // (compile-time after unrolling: pl and row_bytes are constants)
 #define RL_CASE(V) case V: store_dword_saddr_nt<V>(sb, lane_off, pk); break;
-                RL_CASE(0) RL_CASE(128) RL_CASE(256) RL_CASE(384) RL_CASE(512) RL_CASE(640) RL_CASE(768) RL_CASE(896)
-                RL_CASE(1024) RL_CASE(1152) RL_CASE(1280) RL_CASE(1408) RL_CASE(1536) RL_CASE(1664) RL_CASE(1792) RL_CASE(1920)
-                RL_CASE(2048) RL_CASE(2176) RL_CASE(2304) RL_CASE(2432) RL_CASE(2560) RL_CASE(2688) RL_CASE(2816) RL_CASE(2944)
-                RL_CASE(3072) RL_CASE(3200) RL_CASE(3328) RL_CASE(3456) RL_CASE(3584) RL_CASE(3712) RL_CASE(3840) RL_CASE(3968)
+                  RL_CASE(0) RL_CASE(128) RL_CASE(256) RL_CASE(384) RL_CASE(512) RL_CASE(640) RL_CASE(768) RL_CASE(896)
+                  RL_CASE(1024) RL_CASE(1152) RL_CASE(1280) RL_CASE(1408) RL_CASE(1536) RL_CASE(1664) RL_CASE(1792) RL_CASE(1920)
+                  RL_CASE(2048) RL_CASE(2176) RL_CASE(2304) RL_CASE(2432) RL_CASE(2560) RL_CASE(2688) RL_CASE(2816) RL_CASE(2944)
+                  RL_CASE(3072) RL_CASE(3200) RL_CASE(3328) RL_CASE(3456) RL_CASE(3584) RL_CASE(3712) RL_CASE(3840) RL_CASE(3968)
 #undef RL_CASE
+                }
               }
             }
           };
-          if (mode1 == 3) fast(std::integral_constant<int, 3>{}); else fast(std::integral_constant<int, 2>{});
+          using T = std::true_type;
+          using F = std::false_type;
+          using M2 = std::integral_constant<int, 2>;
+          using M3 = std::integral_constant<int, 3>;
+          if (nvalid == 32) { if (mode1 == 3) fast(M3{}, F{}); else fast(M2{}, F{}); }
+          else { if (mode1 == 3) fast(M3{}, T{}); else fast(M2{}, T{}); }
         } else {
-          // partial tiles and s8 output: conv_mfma.cuh's pixel-pair emitter (predicated stores beyond the tile's end)
+          // s8 output: conv_mfma.cuh's pixel-pair emitter (optional ReLU, signed saturation; predicated stores
+          // beyond a partial tile's end)
           int ia[G];
           v2f fb[G], fc[G];
 #pragma unroll
@@ -595,8 +629,9 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
   const int lds_row = LW * IC;                        // bytes per halo-tile row in LDS
   // accumulator start values bits(2^23) + comp + bias of this lane's 16 channels per block: resident, the C
   // operand of each chain's first MFMA
+  constexpr bool START_RESIDENT = RL_WAVES <= 12;  // (16 waves: 128 VGPRs per wave, the start values come from LDS per tile)
   v16i start[OCB];
-  {
+  if (START_RESIDENT) {
     const int h4 = 4 * (lane >> 5);
 #pragma unroll
     for (int r = 0; r < OCB; ++r)
@@ -707,6 +742,18 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
         for (int c = 0; c < ICB; ++c) bb[dx][c] = pb + 16 * ((2 * c + h) ^ sw);
       }
       v16i acc0[OCB];
+      if (!START_RESIDENT) {  // start values of this lane's channels from the constant area
+        int h4s = 4 * h;
+        asm volatile("" : "+v"(h4s));  // (per tile: hoisted, the 32 values would be resident after all)
+#pragma unroll
+        for (int r = 0; r < OCB; ++r)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const v4i iv = *reinterpret_cast<const v4i *>(ia0 + 32 * r + 8 * q + h4s);
+            acc0[r][4 * q + 0] = iv[0]; acc0[r][4 * q + 1] = iv[1];
+            acc0[r][4 * q + 2] = iv[2]; acc0[r][4 * q + 3] = iv[3];
+          }
+      }
       {
         constexpr int NS = 9 * ICB;  // k-steps
         constexpr int RD = RL_RING;
@@ -735,7 +782,7 @@ __global__ __launch_bounds__(RL_THREADS, 3) void conv_mfma_roles_kernel(ConvArgs
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int r = 0; r < OCB; ++r)
-            acc0[r] = mfma_i8(fw[st % RD][r], fbr[st % RD], st == 0 ? start[r] : acc0[r]);  // D0[oc][px]
+            acc0[r] = mfma_i8(fw[st % RD][r], fbr[st % RD], (st == 0 && START_RESIDENT) ? start[r] : acc0[r]);  // D0[oc][px]
           __builtin_amdgcn_sched_barrier(0);
           if (st + RD - 1 < NS) fetch(st + RD - 1, (st + RD - 1) % RD);
         }

@@ -32,7 +32,8 @@ L.dfx_debug_read_stamps.restype = ctypes.c_int
 L.dfx_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
 buf = np.zeros(info.grid * 768, dtype=np.uint64)
 L.dfx_debug_read_stamps(op._h, buf.ctypes.data_as(ctypes.c_void_p), buf.size)
-p = buf[:info.grid * 256].reshape(info.grid, 16, 16).astype(np.float64)[:, :12, :]   # 12 waves
+p = buf[:info.grid * 256].reshape(info.grid, 16, 16).astype(np.float64)
+p = p[:, p[0, :, 13] > 0, :]   # the waves that exist (12 or 16)
 role = p[..., 15]
 print("kernel", info.kernel_name.decode(), "grid", info.grid, "rows/unit", info.rows_per_unit)
 life = p[..., 13] - p[..., 12]
@@ -55,9 +56,8 @@ for r, name, cols in ((0, "A (conv0 + requant 0)", ["wait for the tile's unit", 
             continue
         if c == "entry -> loop":
             print("   %-34s %8.0f cycles" % (c, w[:, k].mean()))
-            if r != 2:
-                print("   start-up: global loads arrived %6.0f, own LDS writes done %6.0f, past the barrier %6.0f (cycles after entry)" % (
-                    w[:, 7].mean(), w[:, 8].mean(), w[:, 9].mean()))
+            print("   start-up: global loads arrived %6.0f, own staging done (at the barrier) %6.0f, past the barrier %6.0f (cycles after entry); entry stamp spread over the workgroup's waves %6.0f cycles" % (
+                w[:, 7].mean(), w[:, 8].mean(), w[:, 9].mean(), (p[..., 12].max(axis=1) - p[..., 12].min(axis=1)).mean()))
         else:
             print("   %-34s %8.0f cycles per %s   (%.1f%% of the wave's lifetime)" % (
                 c, (w[:, k] / n).mean(), "unit" if r == 2 else "tile", 100 * (w[:, k] / (w[:, 13] - w[:, 12])).mean()))
