@@ -386,9 +386,6 @@ __device__ __forceinline__ void store_pixel(unsigned char *p, float (&f)[G], boo
         pk |= b << (8 * c);
       }
     }
-#ifdef DFX_X_NOSTORE  // timing experiment only (profiles/scripts/r3_experiments.sh): compute everything, store nothing
-    if (pk != 0x12345678u) return;
-#endif
     if (G == 4) DFX_STORE(reinterpret_cast<unsigned *>(p), pk);
     else if (G == 2) *reinterpret_cast<unsigned short *>(p) = (unsigned short)pk;
     else *p = (uint8_t)pk;
@@ -608,7 +605,13 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
   // The loaders then start with k = 2, 3.  Needs statically known first units.
   // Stream id of loader `tm` of this workgroup, team-major: a partial last static round (stream ids
   // below total_units % T) then gives every workgroup one more unit instead of two more to half of them.
-  auto stream_id = [&](int tm) { return tm * (int)gridDim.x + (int)blockIdx.x; };
+  // Workgroup id with XCD-major numbering (round 3): hardware deals workgroups round-robin over the 8 XCDs, so
+  // the units of consecutive ids -- vertical neighbours that share two halo rows -- landed on eight different L2s
+  // and every halo row was fetched from HBM twice.  Renumbered (blockIdx % 8 picks the group: speed only),
+  // neighbours run on one XCD in the same round and the second reader hits in L2.
+  const int wg = (gridDim.x % 8 == 0) ? (int)(blockIdx.x % 8) * (int)(gridDim.x / 8) + (int)(blockIdx.x / 8)
+                                      : (int)blockIdx.x;
+  auto stream_id = [&](int tm) { return tm * (int)gridDim.x + wg; };
   const bool coop0 = g.static_rounds >= 1;
   // coop1: each loader stages its second unit (static as well) into slot 2 + team BEFORE the barrier,
   // while the compute waves copy the weights: all four slots are full when the claim loop starts.

@@ -8,49 +8,59 @@
 //   compute1x1_loop / store_1x1output  src/jit_conv_kernel.cc:143-191, :50-141
 //   infer_conv0conv1                   src/op_conv.cc:140-260
 //
-// Why: in conv_mfma.cuh every compute wave walks conv0 (36 MFMAs, LDS-fed) -> requant 0 -> conv1 (16
-// MFMAs) -> requant 1 + stores (256 VALU + 32 stores) one after the other, with ~120 live VGPRs in each
-// phase.  A wave issues in order, so its matrix work and its vector work never overlap, every phase
-// change exposes an LDS round trip (first fragments, 1x1 weights twice, constants), and what overlap
-// there is comes from four waves per SIMD happening to be in different phases: measured 17 % MFMA/VALU
-// co-execution, 27 % matrix-pipe utilisation (round 2: profiles/r02_res2a_u8_rocprofv3_summary.txt).
-// Here the phases are ROLES with their own waves, so a SIMD always holds a matrix-heavy wave next to
-// vector-heavy ones:
-//   * 4 A waves (one per SIMD): conv0 + requant 0.  36 MFMAs per 32-pixel tile back to back, fragments
-//     prefetched through a register ring, accumulators started from resident registers (the MFMA's C
-//     operand) -- no LDS round trip between tiles.  The u8 intermediate (32 pixels x OC bytes = 2 KB, in
-//     the 1x1 MFMA's A-fragment order) goes to a ring of `mid` slots in LDS.  The reference keeps it in
-//     xmm registers (jit_conv_kernel.cc:275-277); here it crosses from one wave's registers to another's
-//     through LDS and never reaches HBM either.
-//   * 6 B waves: conv1 + requant 1 + stores.  The 1x1 weights (OC1 x OC bytes = 64 VGPRs per lane at the
-//     headline shape) stay RESIDENT IN REGISTERS for the whole launch, so a B wave's only LDS traffic per
-//     tile is the 2 KB of `mid`, its constants and three control words.
-//   * 2 loader waves: unchanged (global -> registers -> LDS halo tiles, units from the static split /
-//     device queue).
-//   12 waves x <= 168 VGPRs (3 per SIMD).  LDS traffic per tile drops from 72 KB to 57 KB (no 1x1 weight
-//   or start-value re-reads).
+// Why (round 3 measurements, profiles/r03/):
+//  * In conv_mfma.cuh every compute wave walks conv0 (36 MFMAs, LDS-fed) -> requant 0 -> conv1 (16 MFMAs) ->
+//    requant 1 + stores one after the other.  A wave issues in order, so its matrix work and its vector work never
+//    overlap and every phase change exposes an LDS round trip (first fragments, 1x1 weights twice, constants).
+//  * What the hardware can overlap, measured with tools/probe/probe_coexec.hip and probe_issue.hip: a SIMD issues
+//    ONE vector instruction (VALU or MFMA) per 4 cycles over all of its waves, a scalar one and an LDS one beside
+//    it from other waves; plain VALU instructions run under an MFMA in flight (six per 32-cycle MFMA in one wave's
+//    stream cost nothing, another wave's stream runs at 6.1 instead of 5.3 cycles per instruction), the PACKED f32
+//    forms do not (round 2's v_pk_add / v_pk_mul epilogue, see DFX_PACKED_F32 in conv_mfma.cuh); one wave alone
+//    issues at most one instruction per ~5 cycles of whatever kind.
+//  So: the fewest possible vector instructions per output value (one v_fma_f32 + one v_cvt_pk_u8_f32), no address
+//  or control arithmetic in vector registers, and the phases as ROLES with their own waves, so that a SIMD always
+//  holds matrix-heavy waves next to vector-heavy ones:
+//   * 6 A waves: conv0 + requant 0.  36 MFMAs per 32-pixel tile back to back, fragments prefetched through a
+//     register ring.  The u8 intermediate (32 pixels x OC bytes = 2 KB, in the 1x1 MFMA's A-fragment order) goes
+//     to a ring of `mid` slots in LDS.  The reference keeps it in xmm registers (jit_conv_kernel.cc:275-277); here
+//     it crosses from one wave's registers to another's through LDS and never reaches HBM either.
+//   * 8 B waves: conv1 + requant 1 + stores.  Wave j serves channel group j % NCG (128 output channels) of every
+//     tile: its 1x1 weight fragments (from global memory, once) and its lane's requant constants stay RESIDENT IN
+//     REGISTERS for the whole launch, so a B wave's LDS traffic per visit is the 2 KB of `mid` and three words.
+//   * 2 loader waves: conv_mfma.cuh's (global -> registers -> LDS halo tiles, units from the static split / queue).
+//   16 waves x 128 VGPRs.  LDS traffic per tile drops from 72 KB to ~58 KB (no 1x1 weight or start-value re-reads).
 // Hand-offs are LDS words written and read by whole waves, all control flow scalar (see conv_mfma.cuh):
-//   A: tile claim (ds_append CTL_NEXT) -> conv0 -> count the tile off its input slot (CTL_DONE) ->
-//      requant 0 -> mid slot m = ds_append(MHEAD), wait MFREE[m % NM] -> write mid + {dst pixel, valid
-//      pixels} -> MFULL[m % NM] = generation + 1.
-//   B: b = ds_append(MTAIL) -> wait MFULL[b % NM] -> read mid -> MFREE[b % NM] = generation + 1 -> per
-//      group of 128 output channels: 2 x 4 MFMAs from registers, requant 1 (emit_pair of conv_mfma.cuh),
-//      16 dword stores (a half-wave writes one whole 128-byte line).
-//   End: an A wave that runs out of tiles adds itself to ADONE; a B wave whose claim lies beyond the final
-//      MHEAD leaves.  Every spin is bounded (MFMA_SPIN_LIMIT).
-// The mid ring lives in the LDS area of the packed 1x1 weights, which is dead once every B wave has
-// copied its fragments to registers (W1DONE).
+//   A: tile claim t (ds_append CTL_NEXT) -> unit record of the slot (ONE ds_read_b128: {dst pixel, th/tw, tiles per
+//      row, generation published}) -> conv0 -> count the claim off its input slot (CTL_DONE, lane-0 ds_add) ->
+//      requant 0 -> mid slot t % NM (generation t / NM; wait MFREE) -> write mid + {dst pixel, valid pixels} ->
+//      MFULL.  EVERY claim that is not a wave's last publishes a slot, if only an empty record (valid pixels 0), so
+//      the slots can be walked in claim order and no head counter exists.
+//   B: b = next claim of its group (MTAIL[group], synchronous lane-0 ds_add_rtn placed behind the MFMAs it has just
+//      issued) -> wait MFULL[b % NM] -> read mid -> MFREE += 64 -> 2 x 4 MFMAs from registers -> per pixel 4 x
+//      (v_fma_f32 or v_add_f32 + v_mul_f32, v_cvt_pk_u8_f32) and one global_store_dword with a scalar base: a
+//      half-wave writes one whole 128-byte line, no address instruction.
+//   End: an A wave that runs out of tiles adds itself to ADONE; a B wave whose slot stays empty after that leaves.
+//   Every spin is bounded (RL_SPIN_LIMIT / MFMA_SPIN_LIMIT).
+// The mid ring lives in the LDS area the packed 1x1 weights have in conv_mfma.cuh's LDS image.
+// Start-up: W0 + constants travel global -> LDS by LDS-DMA (no VGPR / ds_write detour), the first two units of
+// each loader stream are staged by the A / B waves in the same memory round trip (the loaders' own set-up used to
+// hold the only workgroup barrier ~3 k cycles).
+// Unit numbering is XCD-major (see `wg`): vertically neighbouring units share an L2, HBM reads 1.03 x the input
+// instead of 1.5 x (PMC FETCH_SIZE 13.3 MB x 2 against 19.2 MB x 2).
 //
 // Requant: stage 0 takes the host-proven "fma" mode only (geom.mode0 == 3): accumulators start from
 // bits(2^23) + comp + bias, so their bits read as the float 2^23 + t for the true sum t = acc + bias >= 0
 // and as 2^23 - |t|/2 (the binade below: still negative after the subtraction) for t < 0; one
-// v_pk_fma_f32(x, s, -2^23 s) then yields t*s with the reference's single rounding (2^23 s is exact) for
+// v_fma_f32(x, s, -2^23 s) then yields t*s with the reference's single rounding (2^23 s is exact) for
 // t >= 0 and some negative number for t < 0, which the stage's ReLU + unsigned saturation turns into 0
-// exactly as they do the reference's negative product -- 1.5 VALU instructions per value instead of 2.
-// Needs s >= 0.  Stage 1 takes the "magic" mode of conv_mfma.cuh (geom.mode1 == 2).  Everything else (exact
-// x86 overflow semantics, round-down, negative scales, 4-byte outputs) stays on conv_mfma.cuh.
+// exactly as they do the reference's negative product.  Needs s >= 0.  Stage 1 takes conv_mfma.cuh's "magic" mode
+// (geom.mode1 == 2: add + mul) or, where every channel's addend (comp + bias - m / ulp) * scale is exactly
+// representable (power-of-two scales and a few others, proven per channel by the host), one v_fma_f32
+// (geom.mode1 == 3).  Everything else (exact x86 overflow semantics, round-down, negative scales, 4-byte outputs)
+// stays on conv_mfma.cuh.
 //
-// Supported: what conv_mfma.cuh supports, with oc1x1 a multiple of 128 and (oc1x1 / 32) * (oc / 32) <= 16.
+// Supported: what conv_mfma.cuh supports, with 1-byte output and oc1x1 a multiple of 128 up to 512.
 #pragma once
 
 #include "conv_mfma.cuh"
@@ -79,7 +89,6 @@ constexpr int RL_SPIN_LIMIT = 1 << 19;               // bound of the s_sleep(4) 
 // control words (ints) behind those of conv_mfma.cuh (CTL_*, < 32)
 constexpr int RCTL_ADONE = 33;   // 64 x A waves that have left
 constexpr int RCTL_MTAIL = 36;   // [4] per channel group: 64 x mid slots claimed by the group's B waves
-constexpr int RCTL_W1DONE = 34;  // 64 x B waves that hold their 1x1 fragments in registers
 constexpr int RCTL_MFULL = 40;   // [8] generations published into mid slot s
 constexpr int RCTL_MFREE = 48;   // [8] 64 x reads of mid slot s counted off (NCG per generation: one per channel group)
 constexpr int RCTL_MINFO = 64;   // [8][4] per mid slot: dst pixel index of the tile's first pixel, valid pixels
@@ -395,10 +404,15 @@ __global__ __launch_bounds__(RL_THREADS, (RL_WAVES + 3) / 4) void conv_mfma_role
     {
       typedef __attribute__((address_space(3))) void lds_void;
       typedef __attribute__((address_space(1))) const void global_void;
+      // (the image is [W0 | W1 | constants] in global memory and in LDS; the W1 part of LDS is the mid ring, the
+      // B waves take their 1x1 fragments from global memory themselves)
+      constexpr int w1_first = OCB * 9 * ICB * 64, w1_end = w1_first + NCB * OCB * 64;  // 16-byte chunks
       const int nblk = (total + 63) >> 6;  // 1 KB blocks
-      for (int j = wave; j < nblk; j += RL_C)
-        if (64 * j + lane < total)
-          __builtin_amdgcn_global_load_lds((global_void *)(s + 64 * j + lane), (lds_void *)(d + 64 * j), 16, 0, 0);
+      for (int j = wave; j < nblk; j += RL_C) {
+        const int q = 64 * j + lane;
+        if (q < total && (q < w1_first || q >= w1_end))
+          __builtin_amdgcn_global_load_lds((global_void *)(s + q), (lds_void *)(d + 64 * j), 16, 0, 0);
+      }
       // The first TWO units of stream `steam` (both static: coop0 / coop1): all their global loads are issued
       // before the first LDS write.  (Until round 3 the loader staged its second unit itself before the barrier:
       // its table set-up put those loads ~3 k cycles behind everybody else's and the whole workgroup waited at the
@@ -482,20 +496,18 @@ __global__ __launch_bounds__(RL_THREADS, (RL_WAVES + 3) / 4) void conv_mfma_role
     constexpr unsigned row_bytes = OC1;  // dst bytes per pixel
     const int l31 = lane & 31, h4 = 4 * (lane >> 5);
     const int chb = 32 * G * cg + G * l31;  // this lane's first channel
-    v4i w1r[G][OCB];
+    v4i w1r[G][OCB];  // straight from global memory (L2): the 1x1 weights never pass through LDS
 #pragma unroll
     for (int cc = 0; cc < G; ++cc)
 #pragma unroll
       for (int r = 0; r < OCB; ++r)
-        w1r[cc][r] = *reinterpret_cast<const v4i *>(w1s + ((cg * G + cc) * OCB + r) * 1024 + lane * 16);
+        w1r[cc][r] = *reinterpret_cast<const v4i *>(a.wei1 + ((cg * G + cc) * OCB + r) * 1024 + lane * 16);
     float fbk[G], fck[G];
 #pragma unroll
     for (int cc = 0; cc < G; ++cc) {
       fbk[cc] = pb1[2 * (chb + cc)];
       fck[cc] = pc1[2 * (chb + cc)];
     }
-    // (LDS executes a wave's DS instructions in order: the add below follows the reads above)
-    __hip_atomic_fetch_add(ctrl + RCTL_W1DONE, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // all lanes: + 64
     const unsigned lane_off = (unsigned)h4 * row_bytes + (unsigned)chb;
     int v64 = 64;  // (one VGPR for the whole loop)
     asm volatile("" : "+v"(v64));
@@ -536,11 +548,7 @@ __global__ __launch_bounds__(RL_THREADS, (RL_WAVES + 3) / 4) void conv_mfma_role
         b = lds_add_rtn_lane0_sync(4 * (RCTL_MTAIL + cg), v64) >> 6;
         continue;
       }
-#ifndef DFX_X_LOCALSTORE
       unsigned char *tile_dst = reinterpret_cast<unsigned char *>(a.dst) + (size_t)obase_i * row_bytes;
-#else  // timing experiment only: every tile of a workgroup is written to the same 8 KB (stays in L2, no HBM writes)
-      unsigned char *tile_dst = reinterpret_cast<unsigned char *>(a.dst) + (size_t)blockIdx.x * 32 * row_bytes + (obase_i & 0);
-#endif
       const int mode1 = g.mode1;
       {
         v16i acc1[G];
@@ -549,6 +557,7 @@ __global__ __launch_bounds__(RL_THREADS, (RL_WAVES + 3) / 4) void conv_mfma_role
 #pragma unroll
           for (int cc = 0; cc < G; ++cc)
             acc1[cc] = r == 0 ? mfma_i8_from_magic(mid[0], w1r[cc][0]) : mfma_i8(mid[r], w1r[cc][r], acc1[cc]);
+
         if (OCB == 1) asm volatile("s_nop 7\n\ts_nop 4" ::: "memory");  // (asm MFMA results: see conv_mfma.cuh)
         // the next claim, behind the MFMAs just issued: its LDS round trip passes while they execute
         b = lds_add_rtn_lane0_sync(4 * (RCTL_MTAIL + cg), v64) >> 6;
@@ -659,7 +668,6 @@ __global__ __launch_bounds__(RL_THREADS, (RL_WAVES + 3) / 4) void conv_mfma_role
     k = g.ntu == 1 ? t : (int)__umulhi((unsigned)t, g.ntu_magic);
     ti = t - k * g.ntu;
   };
-  bool w1_gone = false;  // every B wave holds its 1x1 fragments in registers: the mid ring may be written
   int c_ahead = 0;
   int t = __builtin_amdgcn_readfirstlane(draw()) >> 6, k, ti;
   split(t, k, ti);
@@ -762,18 +770,11 @@ __global__ __launch_bounds__(RL_THREADS, (RL_WAVES + 3) / 4) void conv_mfma_role
           const int tap = st / ICB, c = st % ICB;
           // issue order = reverse of the use order (the step's first MFMA takes fw[0] and fbr): one s_waitcnt before
           // the first MFMA then covers the whole step (a wave's LDS reads return in order)
-#ifdef DFX_X_OLDFETCH
-          fbr[slot] = *reinterpret_cast<const v4i *>(ins + (tap / 3) * lds_row + bb[tap % 3][c]);
-#pragma unroll
-          for (int r = 0; r < OCB; ++r)
-            fw[slot][r] = *reinterpret_cast<const v4i *>(w0s + ((r * 9 + tap) * ICB + c) * 1024 + lane16);
-#else
 #pragma unroll
           for (int r = OCB - 1; r >= 1; --r)
             fw[slot][r] = *reinterpret_cast<const v4i *>(w0s + ((r * 9 + tap) * ICB + c) * 1024 + lane16);
           fbr[slot] = *reinterpret_cast<const v4i *>(ins + (tap / 3) * lds_row + bb[tap % 3][c]);
           fw[slot][0] = *reinterpret_cast<const v4i *>(w0s + ((0 * 9 + tap) * ICB + c) * 1024 + lane16);
-#endif
         };
 #pragma unroll
         for (int st = 0; st < RD - 1; ++st) fetch(st, st);
@@ -826,10 +827,6 @@ __global__ __launch_bounds__(RL_THREADS, (RL_WAVES + 3) / 4) void conv_mfma_role
       DFX_STAMP(a3);
       // ---- publish into the mid ring ----
       const int ms = t_cur & (NM - 1), mgen = t_cur >> LOG_NM;
-      if (!w1_gone) {
-        for (int spin = 0; spin < RL_SPIN_LIMIT && ctl_load(RCTL_W1DONE) < 64 * RL_B; ++spin) __builtin_amdgcn_s_sleep(1);
-        w1_gone = true;
-      }
       for (int spin = 0; spin < RL_SPIN_LIMIT && ctl_load(RCTL_MFREE + ms) < 64 * NCG * mgen; ++spin) __builtin_amdgcn_s_sleep(4);
       DFX_STAMP(a4);
       unsigned char *mslot = w1s + ms * (OCB * 1024);
