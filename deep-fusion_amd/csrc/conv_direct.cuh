@@ -22,14 +22,27 @@
 //    store path of conv_mfma.cuh), A fragments from mid, B fragments from global.
 // Three workgroup barriers per unit in all.  Requantisation, fast/exact paths, the LDS
 // transpose for 1-byte outputs and the unit geometry are those of conv_stream.cuh.
+//
+// Round 3:
+//  * A unit has NPB = 1, 2 or 4 blocks of 32 pixel slots (it used to be 4 always: a 14x14 or 7x7 layer
+//    then yields 196 / 64 units for 512 workgroup slots, one wave per SIMD on the CUs that get any).
+//    The four waves split output blocks WO ways and pixel blocks WP = 4 / WO ways in conv0 (PXW =
+//    NPB / WP pixel blocks per wave), WO1 x WP1 in conv1: with one pixel block per unit every wave
+//    streams its own quarter of BOTH weight sets (before, every wave streamed the whole 1x1 set).
+//    The host picks the largest NPB that still fills three quarters of the workgroup slots.
+//  * Requant without int -> float conversions where the host proves the ranges (dfx_api.hip, as for
+//    conv_mfma_roles.cuh): stage 0 "fma" (g.m0: accumulators start from bits(2^23) + comp + bias, one
+//    v_fma_f32 + v_cvt_pk_u8_f32 per value), stage 1 "magic" (g.m1 = 2: start 1/(2 pi), v_add_f32 +
+//    v_mul_f32 + cvt; g.m1 = 3: one v_fma_f32 where the addend is exact) for u8 output -- 2 to 3 vector
+//    instructions per value instead of 5 (the requant + store stage was the longest of a unit: 14.8 k of
+//    52 k cycles at res4, profiles/stamps_direct.py).
 #pragma once
 
 #include "conv_mfma.cuh"
 
 namespace dfx {
 
-constexpr int DK_THREADS = 256;
-constexpr int DK_M = 128;    // pixel slots per unit
+constexpr int DK_M = 128;    // pixel slots per unit at most (NPB = 4 blocks of 32)
 constexpr int DK_POS = 80;   // LDS bytes per halo-tile position and plane (64 + 16 pad)
 constexpr int DK_TQ = 4;     // tile granules a thread prefetches into registers
 constexpr int DK_RD = 9;     // conv0 weight ring: k-blocks in flight per wave (multiple of 3)
@@ -47,6 +60,8 @@ struct DirectGeom {
   int mid_stride;       // 32 * ocb + 16
   int off_pxoff, off_mid, off_cst;  // LDS byte offsets (tile and the aliased staging at 0)
   int fast;             // 1: fast requant path valid (host proof)
+  int m0, m1;           // host-proven requant without conversions: m0 = 1 stage-0 "fma"; m1 = 2 / 3 stage-1 "magic" / "fma"
+  int npb;              // 32-pixel blocks per unit (1, 2 or 4)
 #ifdef DFX_STAMPS
   unsigned long long *prof;  // diagnostic build only: [workgroup][wave][16] cycle sums
 #endif
@@ -75,14 +90,22 @@ struct DirectGeom {
 #define DK_CHK(TAG, OFF, LEN, SIZE) (OFF)
 #endif
 
-template <int WO, int G, int WO1, int DST>
-__global__ __launch_bounds__(DK_THREADS, 2) void conv_direct_kernel(ConvArgs a, DirectGeom g) {
+// NW waves per workgroup: 4 (two workgroups per CU where the units and the LDS allow) or 8 (one workgroup per CU,
+// two waves per SIMD: layers whose 128-pixel units do not even fill the CUs once)
+template <int NW, int WO, int G, int WO1, int DST, int NPB>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(ConvArgs a, DirectGeom g) {
+  constexpr int DK_THREADS = 64 * NW;
   constexpr int ESZ = (DST == DFX_F32 || DST == DFX_S32) ? 4 : 1;
-  constexpr int WP = 4 / WO, PXW = WO;        // conv0: WO x WP waves, PXW pixel blocks per wave
-  constexpr int WP1 = 4 / WO1, PXW1 = WO1;    // conv1 likewise
-  constexpr int PX1 = PXW1 > 2 ? 2 : PXW1;    // pixel blocks per conv1 pass (accumulator budget)
+  constexpr int WP = NW / WO, PXW = NPB / WP;        // conv0: WO x WP waves, PXW pixel blocks per wave
+  constexpr int WP1 = NW / WO1, PXW1 = NPB / WP1;    // conv1 likewise
+  static_assert(WO * WP == NW && WO1 * WP1 == NW && WP * PXW == NPB && WP1 * PXW1 == NPB && PXW >= 1 && PXW1 >= 1,
+                "wave split must tile the unit's pixel blocks");
+  constexpr int PX1 = G == 4 ? 1 : (PXW1 > 2 ? 2 : PXW1);  // pixel blocks per conv1 pass (accumulators: PX1 * G * 16 VGPRs; with 128 hipcc spills whole accumulators around the epilogue's mode branches)
   constexpr int NP1 = PXW1 / PX1;             // conv1 passes per group
-  constexpr int RD1 = 4;                      // conv1 weight ring depth in k-blocks (G fragments each)
+  // conv1 weight ring depth in k-blocks (G fragments each).  Even, and it divides ocb (a multiple of WO): the
+  // ring never has to stop at the end of a group.
+  constexpr int RD1 = (WO % 4 != 0 || PX1 * G > 4) ? 2 : 4;
+  static_assert(WO % RD1 == 0, "the conv1 ring must divide the number of output blocks");
   constexpr int NF = PXW < 2 ? PXW : 2;       // MFMAs issued before the k-block's LDS prefetch
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *const tile0 = smem;
@@ -97,8 +120,8 @@ __global__ __launch_bounds__(DK_THREADS, 2) void conv_direct_kernel(ConvArgs a, 
   const int OCP = 32 * g.ocb, OC1P = 32 * G * g.n_g1;
   const int *comp0 = reinterpret_cast<const int *>(cst0);
   const float *bias0 = cst0 + OCP, *scale0 = cst0 + 2 * OCP;
-  const int *comp1 = reinterpret_cast<const int *>(a.consts + 3 * OCP);
-  const float *bias1 = a.consts + 3 * OCP + OC1P, *scale1 = a.consts + 3 * OCP + 2 * OC1P;
+  const int *comp1 = reinterpret_cast<const int *>(cst0 + 3 * OCP);  // (LDS as well: a global load in the store epilogue would wait for the weight ring)
+  const float *bias1 = cst0 + 3 * OCP + OC1P, *scale1 = cst0 + 3 * OCP + 2 * OC1P;
   const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const int ntap = a.kh * a.kw, nkb0 = g.icb * ntap;
   // weights: a.wei = W0d[ocb][nkb0][64 lanes][16 B], a.wei1 = W1d[n_g1][ocb][G][64 lanes][16 B]
@@ -154,6 +177,11 @@ __global__ __launch_bounds__(DK_THREADS, 2) void conv_direct_kernel(ConvArgs a, 
     }                                                                                   \
   } while (0)
 
+  // buffer resources of the two weight arrays (raw, range-checked: W0d ocb * nkb0 KB, W1d n_g1 * ocb * G KB).
+  // With flat addresses hipcc hoisted one 64-bit per-lane pointer per ring slot out of the unit loop and
+  // spilled them (70-84 VGPRs, ~20 k cycles of scratch reloads per unit).
+  const __amdgpu_buffer_rsrc_t w0rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(a.wei), 0, g.ocb * nkb0 * 1024, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w1rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(a.wei1), 0, g.n_g1 * g.ocb * G * 1024, 0x00020000);
   const int upg = g.uy * g.ux;
   struct UnitGeo { int n0, y0, x0, nimg, iy0, ix0; };
   auto unit_geo = [&](int unit) {
@@ -166,7 +194,7 @@ __global__ __launch_bounds__(DK_THREADS, 2) void conv_direct_kernel(ConvArgs a, 
     return r;
   };
 
-  for (int q = tid; q < 3 * OCP; q += DK_THREADS)  // visible after the first barrier
+  for (int q = tid; q < 3 * (OCP + OC1P); q += DK_THREADS)  // visible after the first barrier
     cst0[q] = a.consts[DK_CHK(3, (long long)q * 4, 4, g.cst_bytes) / 4];
 #ifdef DFX_STAMPS
   unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -174,6 +202,10 @@ __global__ __launch_bounds__(DK_THREADS, 2) void conv_direct_kernel(ConvArgs a, 
 
   for (int unit = blockIdx.x; unit < g.total_units; unit += gridDim.x) {
     const UnitGeo ug = unit_geo(unit);
+    // (keeps the staging table's decoded fields and addresses from being hoisted out of the unit loop: as loop
+    // invariants they outlived both K loops and were spilled)
+#pragma unroll
+    for (int i = 0; i < DK_TQ; ++i) asm volatile("" : "+v"(tq_pos[i]));
     const int thc = min(g.thv, a.oh - ug.y0), twc = min(g.twv, a.ow - ug.x0);
     const int npx = ug.nimg * thc * twc;
     DFX_STAMP(t0);
@@ -181,7 +213,7 @@ __global__ __launch_bounds__(DK_THREADS, 2) void conv_direct_kernel(ConvArgs a, 
     __syncthreads();
     // ---- stage the whole halo tile (all planes) ----
     DK_T_ISSUE(ug.n0, ug.iy0, ug.ix0, ug.nimg);
-    {  // slot table: wave w fills pixel block w
+    if (wave < NPB) {  // slot table: wave w fills pixel block w
       const int slot = 32 * wave + l31;
       const int pc = min(slot, npx - 1);
       const int img = pc / (thc * twc), r = pc - img * (thc * twc);
@@ -219,51 +251,10 @@ __global__ __launch_bounds__(DK_THREADS, 2) void conv_direct_kernel(ConvArgs a, 
       fbyte[p] = (img * lhw + ty * a.sh * g.lw + tx * a.sw) * DK_POS + 16 * h;
       mid_w[p] = mid + slot * g.mid_stride + h * 16;
     }
-    for (int ob = wo; ob < g.ocb; ob += WO) {
-      DFX_STAMP(t1b);
-      v16i acc[PXW];
-#pragma unroll
-      for (int p = 0; p < PXW; ++p) acc[p] = zero16;
-      v4i wr[DK_RD];
-#pragma unroll
-      for (int i = 0; i < DK_RD; ++i)
-        wr[i] = *reinterpret_cast<const v4i *>(reinterpret_cast<const char *>(a.wei) + DK_CHK(4, ((long long)ob * nkb0 + min(i, nkb0 - 1)) * 1024 + lane * 16, 16, g.wei_bytes));
-      // position of the NEXT k-block whose pixel fragments get loaded (runs two ahead)
-      int l_tap = 0, l_tkw = 0, l_toff = 0, l_icb = 0;
-      v4i fb[3][PXW];
-#define DK_LOAD_FB(SET)                                                                 \
-  do {                                                                                  \
-    const int koff_ = __builtin_amdgcn_readfirstlane((l_icb >> 1) * g.plane_bytes + (l_icb & 1) * 32 + l_toff); \
-    _Pragma("unroll") for (int p = 0; p < PXW; ++p)                                     \
-      fb[SET][p] = *reinterpret_cast<const v4i *>(tile0 + fbyte[p] + koff_);            \
-    l_toff += DK_POS;                                                                   \
-    if (++l_tkw == a.kw) { l_tkw = 0; l_toff += row_skip; }                             \
-    if (++l_tap == ntap) { l_tap = 0; l_tkw = 0; l_toff = 0; ++l_icb; }                 \
-  } while (0)
-      DK_LOAD_FB(0);
-      if (nkb0 > 1) DK_LOAD_FB(1);
-      DKF();
-      for (int kb0 = 0; kb0 < nkb0; kb0 += DK_RD) {
-#pragma unroll
-        for (int i = 0; i < DK_RD; ++i) {
-          const int kb = kb0 + i;
-          if (kb < nkb0) {
-#pragma unroll
-            for (int p = 0; p < NF; ++p) acc[p] = mfma_i8(wr[i], fb[i % 3][p], acc[p]);  // D0[oc][px]
-            DKF();
-            if (kb + 2 < nkb0) DK_LOAD_FB((i + 2) % 3);
-            DKF();
-#pragma unroll
-            for (int p = NF; p < PXW; ++p) acc[p] = mfma_i8(wr[i], fb[i % 3][p], acc[p]);
-            DKF();
-            // refill the ring slot (returns ~1k cycles later)
-            wr[i] = *reinterpret_cast<const v4i *>(reinterpret_cast<const char *>(a.wei) + DK_CHK(5, ((long long)ob * nkb0 + min(kb + DK_RD, nkb0 - 1)) * 1024 + lane * 16, 16, g.wei_bytes));
-          }
-        }
-      }
-#undef DK_LOAD_FB
-      DFX_STAMP(t2);
-      // requant 0 -> u8 -> mid, in the 1x1 stage's k order: byte 16h + 4q + i of block ob = channel 32 ob + 8q + 4h + i
+    // requant 0 -> u8 -> mid, in the 1x1 stage's k order: byte 16h + 4q + i of block ob = channel 32 ob + 8q + 4h + i.
+    // MODE 2: "fma" (bias slot = -2^23 * scale, see conv_mfma_roles.cuh), 1: fast, 0: exact
+    auto requant0 = [&](auto mode_tag, int ob, const v16i(&acc)[PXW]) {
+      constexpr int MODE = decltype(mode_tag)::value;
 #pragma unroll
       for (int p = 0; p < PXW; ++p) {
         v4i pkv;
@@ -273,7 +264,11 @@ __global__ __launch_bounds__(DK_THREADS, 2) void conv_direct_kernel(ConvArgs a, 
           const v4f bs = *reinterpret_cast<const v4f *>(bias0 + ch);
           const v4f sc = *reinterpret_cast<const v4f *>(scale0 + ch);
           unsigned pk = 0;
-          if (fast) {
+          if constexpr (MODE == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              pk = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(__int_as_float(acc[p][4 * q + i]), sc[i], bs[i]), i, pk);
+          } else if constexpr (MODE == 1) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)  // plain v_add_f32 / v_mul_f32: the packed forms do not overlap with MFMAs (conv_mfma.cuh)
               pk = __builtin_amdgcn_cvt_pk_u8_f32(__fmul_rn(__fadd_rn(__int2float_rn(acc[p][4 * q + i]), bs[i]), sc[i]), i, pk);
@@ -289,131 +284,278 @@ __global__ __launch_bounds__(DK_THREADS, 2) void conv_direct_kernel(ConvArgs a, 
         }
         *reinterpret_cast<v4i *>(mid_w[p] + ob * 32) = pkv;
       }
-      DFX_STAMP(t3);
-      DFX_ACC(2, t3 - t2);  // requant 0
-      DFX_ACC(1, t2 - t1b);  // conv0 K loop
+    };
+    // The weight fragments of this wave are ONE stream of 1 KB blocks (output blocks wo, wo + WO, ...; k-blocks
+    // 0 .. nkb0 - 1 of each) fetched through a ring of DK_RD registers quadruples.  The K loop is branch-free
+    // around its loads: hipcc's wait-count pass merges the states of the two sides of a branch, so a load inside
+    // a conditional made it count the ring down to vmcnt(0) once per DK_RD k-blocks (round 2 / early round 3:
+    // the ring was drained every 9 k-blocks, 85 cycles per MFMA at res4).  EVEN (nkb0 a multiple of DK_RD, every
+    // 3x3 layer): refills run on into the next output block, the requant of one block hides under the loads of
+    // the next.  Otherwise whole rounds are branch-free and the last k-blocks of a block run unpipelined.
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const int ob_last = wo + (g.ocb - 1 - wo) / WO * WO;
+    auto conv0_stage = [&](auto even_tag) {
+      constexpr bool EVEN = decltype(even_tag)::value;
+      int r_ob = wo, r_kb = 0;  // next block the ring fetches
+      auto r_next = [&]() -> unsigned {  // its index in W0d, then advance (past the stream's end: the last output block again)
+        const unsigned idx = (unsigned)(min(r_ob, ob_last) * nkb0 + r_kb);
+        const bool wrap = r_kb + 1 == nkb0;
+        r_kb = wrap ? 0 : r_kb + 1;
+        r_ob = wrap ? r_ob + WO : r_ob;
+        return idx;
+      };
+      auto wload = [&](unsigned idx) -> v4i {  // buffer_load_dwordx4 v, lane16, rsrc, soffset: no per-lane 64-bit addresses
+        return __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(w0rs, (int)lane16, (int)(idx << 10), 0));
+      };
+      v4i wr[DK_RD];
+      int l_tap = 0, l_tkw = 0, l_toff = 0, l_icb = 0;  // position of the NEXT k-block whose pixel fragments get loaded (runs two ahead)
+      v4i fb[3][PXW];
+#define DK_LOAD_FB(SET)                                                                 \
+  do {                                                                                  \
+    const int koff_ = __builtin_amdgcn_readfirstlane((l_icb >> 1) * g.plane_bytes + (l_icb & 1) * 32 + l_toff); \
+    _Pragma("unroll") for (int p = 0; p < PXW; ++p)                                     \
+      fb[SET][p] = *reinterpret_cast<const v4i *>(tile0 + fbyte[p] + koff_);            \
+    l_toff += DK_POS;                                                                   \
+    if (++l_tkw == a.kw) { l_tkw = 0; l_toff += row_skip; }                             \
+    if (++l_tap == ntap) { l_tap = 0; l_tkw = 0; l_toff = 0; if (++l_icb == g.icb) l_icb = 0; } \
+  } while (0)
+      if (EVEN) {
+#pragma unroll
+        for (int i = 0; i < DK_RD; ++i) wr[i] = wload(r_next());
+        DK_LOAD_FB(0);
+        DK_LOAD_FB(1);
+      }
+      for (int ob = wo; ob < g.ocb; ob += WO) {
+        DFX_STAMP(t1b);
+        if (!EVEN) {
+          r_ob = ob; r_kb = 0;
+#pragma unroll
+          for (int i = 0; i < DK_RD; ++i) wr[i] = wload(r_next());
+          l_tap = l_tkw = l_toff = l_icb = 0;
+          DK_LOAD_FB(0);
+          DK_LOAD_FB(1);
+        }
+        v16i acc[PXW];
+        if (g.m0) {  // "fma": start from bits(2^23) + comp + bias of this lane's 16 channels (comp slot of the constants)
+          v16i st;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const v4i iv = *reinterpret_cast<const v4i *>(comp0 + ob * 32 + 8 * q + 4 * h);
+            st[4 * q + 0] = iv[0]; st[4 * q + 1] = iv[1]; st[4 * q + 2] = iv[2]; st[4 * q + 3] = iv[3];
+          }
+#pragma unroll
+          for (int p = 0; p < PXW; ++p) acc[p] = st;
+        } else {
+#pragma unroll
+          for (int p = 0; p < PXW; ++p) acc[p] = zero16;
+        }
+        DKF();
+        int kb0 = 0;
+        for (; kb0 + DK_RD <= nkb0; kb0 += DK_RD) {
+#pragma unroll
+          for (int i = 0; i < DK_RD; ++i) {
+#pragma unroll
+            for (int p = 0; p < NF; ++p) acc[p] = mfma_i8(wr[i], fb[i % 3][p], acc[p]);  // D0[oc][px]
+            DKF();
+            DK_LOAD_FB((i + 2) % 3);
+            DKF();
+#pragma unroll
+            for (int p = NF; p < PXW; ++p) acc[p] = mfma_i8(wr[i], fb[i % 3][p], acc[p]);
+            DKF();
+            wr[i] = wload(r_next());  // refill the ring slot (returns ~1k cycles later)
+            DKF();
+          }
+        }
+        if (!EVEN) {
+#pragma unroll
+          for (int i = 0; i < DK_RD; ++i) {
+            if (kb0 + i < nkb0) {
+#pragma unroll
+              for (int p = 0; p < PXW; ++p) acc[p] = mfma_i8(wr[i], fb[i % 3][p], acc[p]);
+              if (kb0 + i + 2 < nkb0) DK_LOAD_FB((i + 2) % 3);
+            }
+          }
+        }
+        DFX_STAMP(t2);
+        if (g.m0) requant0(std::integral_constant<int, 2>{}, ob, acc);
+        else if (fast) requant0(std::integral_constant<int, 1>{}, ob, acc);
+        else requant0(std::integral_constant<int, 0>{}, ob, acc);
+        DFX_STAMP(t3);
+        DFX_ACC(2, t3 - t2);  // requant 0
+        DFX_ACC(1, t2 - t1b);  // conv0 K loop
+      }
+#undef DK_LOAD_FB
+    };
+    if (nkb0 % DK_RD == 0) conv0_stage(TT{}); else conv0_stage(FF{});
+
+    // ---- conv1: this wave's groups x its PXW1 pixel blocks, PX1 at a time ----
+    // Same scheme: the W1 fragments of this wave are one stream of blocks of G fragments (groups wo1, wo1 + WO1,
+    // ...; NP1 passes over each; k-blocks 0 .. ocb - 1) through a ring RD1 blocks deep that is primed BEFORE the
+    // barrier and runs on under the store epilogues.
+    const bool has1 = wo1 < g.n_g1;
+    const int g1_last = has1 ? wo1 + (g.n_g1 - 1 - wo1) / WO1 * WO1 : 0;
+    int r_g = wo1, r_pp = 0, r_blk = 0;
+    auto r1_next = [&]() -> unsigned {
+      const unsigned idx = (unsigned)((min(r_g, g1_last) * g.ocb + r_blk) * G);
+      const bool wrap = r_blk + 1 == g.ocb;
+      const bool wrap2 = wrap && r_pp + 1 == NP1;
+      r_blk = wrap ? 0 : r_blk + 1;
+      r_pp = wrap2 ? 0 : (wrap ? r_pp + 1 : r_pp);
+      r_g = wrap2 ? r_g + WO1 : r_g;
+      return idx;
+    };
+    auto w1load = [&](unsigned idx) -> v4i {
+      return __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(w1rs, (int)lane16, (int)(idx << 10), 0));
+    };
+    v4i wr1[RD1][G];
+#pragma unroll
+    for (int i = 0; i < RD1; ++i) {
+      const unsigned idx = r1_next();
+#pragma unroll
+      for (int cc = 0; cc < G; ++cc) wr1[i][cc] = w1load(idx + cc);
     }
     DFX_STAMP(t4);
     __syncthreads();  // mid is complete; the tile is dead (the store staging may use it)
     DFX_STAMP(t5);
     DFX_ACC(3, t5 - t4);  // barrier after conv0
 
-    // ---- conv1: this wave's groups x its PXW1 pixel blocks, PX1 at a time ----
-    v4i wr1[RD1][G];  // W1 fragments of the next k-blocks of this wave's (group, pass) sequence
-#define DK_W1_PRELOAD(G1)                                                               \
-  _Pragma("unroll") for (int i = 0; i < RD1; ++i)                                       \
-    _Pragma("unroll") for (int cc = 0; cc < G; ++cc)                                    \
-      wr1[i][cc] = *reinterpret_cast<const v4i *>(reinterpret_cast<const char *>(a.wei1) + \
-          DK_CHK(6, (((long long)(G1) * g.ocb + min(i, g.ocb - 1)) * G + cc) * 1024 + lane * 16, 16, g.wei1_bytes))
-    DK_W1_PRELOAD(wo1);
-    for (int g1 = wo1; g1 < g.n_g1; g1 += WO1) {
-      const int chb = 32 * G * g1 + G * l31;
-      int cp[G];
-      float bs[G], sc[G], zf[G];
+    if (has1) {
+      v4i fa[2][PX1];
 #pragma unroll
-      for (int cc = 0; cc < G; ++cc) {
-        cp[cc] = fast ? 0 : comp1[DK_CHK(8, (long long)(3 * OCP + chb + cc) * 4, 4, g.cst_bytes) / 4 - 3 * OCP];
-        bs[cc] = bias1[DK_CHK(9, (long long)(3 * OCP + OC1P + chb + cc) * 4, 4, g.cst_bytes) / 4 - 3 * OCP - OC1P];
-        sc[cc] = scale1[DK_CHK(10, (long long)(3 * OCP + 2 * OC1P + chb + cc) * 4, 4, g.cst_bytes) / 4 - 3 * OCP - 2 * OC1P];
-        zf[cc] = 0.0f;
-      }
+      for (int p = 0; p < PX1; ++p)
+        fa[0][p] = *reinterpret_cast<const v4i *>(mid + (32 * (wp1 * PXW1 + p) + l31) * g.mid_stride + h * 16);
+      for (int g1 = wo1; g1 < g.n_g1; g1 += WO1) {
+        const int chb = 32 * G * g1 + G * l31;
 #pragma unroll
-      for (int pp = 0; pp < NP1; ++pp) {
-        DFX_STAMP(t6);
-        const int pb0 = wp1 * PXW1 + pp * PX1;  // first pixel block of this pass
-        unsigned char *mid_r[PX1];
+        for (int pp = 0; pp < NP1; ++pp) {
+          DFX_STAMP(t6);
+          const int pb0 = wp1 * PXW1 + pp * PX1;                        // first pixel block of this pass
+          const int pbn = wp1 * PXW1 + ((pp + 1) % NP1) * PX1;          // ... of the next one
+          const unsigned char *mid_r[PX1], *mid_n[PX1];
 #pragma unroll
-        for (int p = 0; p < PX1; ++p) mid_r[p] = mid + (32 * (pb0 + p) + l31) * g.mid_stride + h * 16;
-        v16i acc1[PX1][G];
+          for (int p = 0; p < PX1; ++p) {
+            mid_r[p] = mid + (32 * (pb0 + p) + l31) * g.mid_stride + h * 16;
+            mid_n[p] = mid + (32 * (pbn + p) + l31) * g.mid_stride + h * 16;
+          }
+          v16i acc1[PX1][G];
+          {
+            const int m1s = g.m1 ? MAGIC1_BITS : 0;  // "magic": the accumulator's bits read as 1/(2 pi) + raw * 2^-26
+            const v16i st1 = {m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s};
 #pragma unroll
-        for (int p = 0; p < PX1; ++p)
+            for (int p = 0; p < PX1; ++p)
 #pragma unroll
-          for (int cc = 0; cc < G; ++cc) acc1[p][cc] = zero16;
-        v4i fa[2][PX1];
+              for (int cc = 0; cc < G; ++cc) acc1[p][cc] = st1;
+          }
+          DKF();
+          constexpr int NM = PX1 * G, NF1 = NM < 2 ? NM : 2;
+          for (int b0 = 0; b0 < g.ocb; b0 += RD1) {
 #pragma unroll
-        for (int p = 0; p < PX1; ++p) fa[0][p] = *reinterpret_cast<const v4i *>(mid_r[p]);
-        DKF();
-        for (int b0 = 0; b0 < g.ocb; b0 += RD1) {
-#pragma unroll
-          for (int i = 0; i < RD1; ++i) {
-            const int blk = b0 + i;
-            if (blk < g.ocb) {
-              constexpr int NM = PX1 * G, NF1 = NM < 2 ? NM : 2;
+            for (int i = 0; i < RD1; ++i) {
+              const int blk = b0 + i;
 #pragma unroll
               for (int m = 0; m < NF1; ++m)
                 acc1[m % PX1][m / PX1] = mfma_i8(fa[i & 1][m % PX1], wr1[i][m / PX1], acc1[m % PX1][m / PX1]);
               DKF();
-              if (blk + 1 < g.ocb) {
+              {  // the next k-block's pixel fragments; behind the last one: the next pass's first
+                const bool last = blk + 1 == g.ocb;
 #pragma unroll
                 for (int p = 0; p < PX1; ++p)
-                  fa[(i + 1) & 1][p] = *reinterpret_cast<const v4i *>(mid_r[p] + (blk + 1) * 32);
+                  fa[(i + 1) & 1][p] = *reinterpret_cast<const v4i *>(last ? mid_n[p] : mid_r[p] + (blk + 1) * 32);
               }
               DKF();
 #pragma unroll
               for (int m = NF1; m < NM; ++m)
                 acc1[m % PX1][m / PX1] = mfma_i8(fa[i & 1][m % PX1], wr1[i][m / PX1], acc1[m % PX1][m / PX1]);
               DKF();
+              {
+                const unsigned idx = r1_next();
 #pragma unroll
-              for (int cc = 0; cc < G; ++cc)  // refill within the group (a clamped repeat at its end is harmless)
-                wr1[i][cc] = *reinterpret_cast<const v4i *>(reinterpret_cast<const char *>(a.wei1) + DK_CHK(7, (((long long)g1 * g.ocb + min(blk + RD1, g.ocb - 1)) * G + cc) * 1024 + lane * 16, 16, g.wei1_bytes));
+                for (int cc = 0; cc < G; ++cc) wr1[i][cc] = w1load(idx + cc);
+              }
+              DKF();
             }
           }
-        }
-        DFX_STAMP(t7);
-        DFX_ACC(4, t7 - t6);  // conv1 K loop
-        // the ring for the next pass / group travels under this store epilogue
-        if (pp + 1 < NP1) { DK_W1_PRELOAD(g1); } else if (g1 + WO1 < g.n_g1) { DK_W1_PRELOAD(g1 + WO1); }
-        // ---- requant 1 + store ----
-        unsigned char *dst_b = reinterpret_cast<unsigned char *>(a.dst);
-        const unsigned chbE = (unsigned)chb * ESZ;
-        auto emit = [&](auto fast_tag) {
-          if constexpr (ESZ == 1 && G == 4) {
-            // 1-byte outputs: transpose 32 px x 128 B through LDS, 16-byte stores (see conv_stream.cuh)
-            unsigned char *stg = tile0 + wave * DK_STAGE;
+          DFX_STAMP(t7);
+          DFX_ACC(4, t7 - t6);  // conv1 K loop
+          // ---- requant 1 + store (constants from LDS: a global load here would wait for the ring) ----
+          unsigned char *dst_b = reinterpret_cast<unsigned char *>(a.dst);
+          const unsigned chbE = (unsigned)chb * ESZ;
+          // MODE 3: "fma", 2: "magic" (u8 through the 16-byte store path only; bias / scale slots hold the mode's B / C,
+          // conv_mfma.cuh emit_pair), 1: fast, 0: exact
+          auto emit = [&](auto mode_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;
+            constexpr bool FAST = MODE != 0;
+            int cp[G];
+            float bs[G], sc[G], zf[G];
 #pragma unroll
-            for (int p = 0; p < PX1; ++p) {
-#pragma unroll
-              for (int e = 0; e < 16; ++e) {
-                int v[G];
-#pragma unroll
-                for (int cc = 0; cc < G; ++cc) v[cc] = acc1[p][cc][e] + cp[cc];
-                const unsigned pk = pack_group<DST, G, decltype(fast_tag)::value>(v, zf, bs, sc, relu1, a.rm1);
-                *reinterpret_cast<unsigned *>(stg + (8 * (e >> 2) + (e & 3) + 4 * h) * 144 + 4 * l31) = pk;
-              }
-#pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                const int c = lane + 64 * k, px = c >> 3, c16 = c & 7;
-                const unsigned off = pxoff[32 * (pb0 + p) + px];
-                const v4i val = *reinterpret_cast<const v4i *>(stg + px * 144 + 16 * c16);
-                if (off != 0xffffffffu && 128 * g1 + 16 * c16 < a.oc1)
-                  DFX_STORE16(reinterpret_cast<v4i *>(dst_b + DK_CHK(11, (long long)(off + 128 * g1 + 16 * c16), 16, g.dst_bytes)), val);
-              }
+            for (int cc = 0; cc < G; ++cc) {
+              cp[cc] = FAST ? 0 : comp1[chb + cc];
+              bs[cc] = bias1[chb + cc];
+              sc[cc] = scale1[chb + cc];
+              zf[cc] = 0.0f;
             }
-          } else {
-            if (chb < a.oc1) {
+            if constexpr (ESZ == 1 && G == 4) {
+              // 1-byte outputs: transpose 32 px x 128 B through LDS, 16-byte stores (see conv_stream.cuh)
+              unsigned char *stg = tile0 + wave * DK_STAGE;
 #pragma unroll
-              for (int p = 0; p < PX1; ++p)
+              for (int p = 0; p < PX1; ++p) {
 #pragma unroll
-                for (int eq = 0; eq < 4; ++eq) {
-                  const v4i o4 = *reinterpret_cast<const v4i *>(pxoff + 32 * (pb0 + p) + 8 * eq + 4 * h);
+                for (int e = 0; e < 16; ++e) {
+                  unsigned pk = 0;
+                  if constexpr (MODE == 3) {
 #pragma unroll
-                  for (int i = 0; i < 4; ++i) {
-                    const unsigned off = (unsigned)o4[i];
-                    if (off != 0xffffffffu) {
-                      int v[G];
+                    for (int cc = 0; cc < G; ++cc)
+                      pk = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(__int_as_float(acc1[p][cc][e]), sc[cc], bs[cc]), cc, pk);
+                  } else if constexpr (MODE == 2) {
 #pragma unroll
-                      for (int cc = 0; cc < G; ++cc) v[cc] = acc1[p][cc][4 * eq + i] + cp[cc];
-                      store_group<DST, G, decltype(fast_tag)::value>(dst_b + DK_CHK(12, (long long)(off + chbE), G * ESZ, g.dst_bytes), v, zf, bs, sc,
-                                                                     relu1, a.rm1);
+                    for (int cc = 0; cc < G; ++cc)
+                      pk = __builtin_amdgcn_cvt_pk_u8_f32(__fmul_rn(__fadd_rn(__int_as_float(acc1[p][cc][e]), bs[cc]), sc[cc]), cc, pk);
+                  } else {
+                    int v[G];
+#pragma unroll
+                    for (int cc = 0; cc < G; ++cc) v[cc] = acc1[p][cc][e] + cp[cc];
+                    pk = pack_group<DST, G, FAST>(v, zf, bs, sc, relu1, a.rm1);
+                  }
+                  *reinterpret_cast<unsigned *>(stg + (8 * (e >> 2) + (e & 3) + 4 * h) * 144 + 4 * l31) = pk;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  const int c = lane + 64 * k, px = c >> 3, c16 = c & 7;
+                  const unsigned off = pxoff[32 * (pb0 + p) + px];
+                  const v4i val = *reinterpret_cast<const v4i *>(stg + px * 144 + 16 * c16);
+                  if (off != 0xffffffffu && 128 * g1 + 16 * c16 < a.oc1)
+                    DFX_STORE16(reinterpret_cast<v4i *>(dst_b + DK_CHK(11, (long long)(off + 128 * g1 + 16 * c16), 16, g.dst_bytes)), val);
+                }
+              }
+            } else {
+              if (chb < a.oc1) {
+#pragma unroll
+                for (int p = 0; p < PX1; ++p)
+#pragma unroll
+                  for (int eq = 0; eq < 4; ++eq) {
+                    const v4i o4 = *reinterpret_cast<const v4i *>(pxoff + 32 * (pb0 + p) + 8 * eq + 4 * h);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                      const unsigned off = (unsigned)o4[i];
+                      if (off != 0xffffffffu) {
+                        int v[G];
+#pragma unroll
+                        for (int cc = 0; cc < G; ++cc) v[cc] = acc1[p][cc][4 * eq + i] + cp[cc];
+                        store_group<DST, G, FAST>(dst_b + DK_CHK(12, (long long)(off + chbE), G * ESZ, g.dst_bytes), v, zf, bs, sc,
+                                                  relu1, a.rm1);
+                      }
                     }
                   }
-                }
+              }
             }
-          }
-        };
-        if (fast) emit(TT{}); else emit(FF{});
-        DFX_STAMP(t8);
-        DFX_ACC(5, t8 - t7);  // requant 1 + stores
+          };
+          if (DST == DFX_U8 && G == 4 && g.m1 == 3) emit(std::integral_constant<int, 3>{});
+          else if (DST == DFX_U8 && G == 4 && g.m1 == 2) emit(std::integral_constant<int, 2>{});
+          else if (fast) emit(std::integral_constant<int, 1>{});
+          else emit(std::integral_constant<int, 0>{});
+          DFX_STAMP(t8);
+          DFX_ACC(5, t8 - t7);  // requant 1 + stores
+        }
       }
     }
     DFX_STAMP(t9);
@@ -422,11 +564,10 @@ __global__ __launch_bounds__(DK_THREADS, 2) void conv_direct_kernel(ConvArgs a, 
   }
 #ifdef DFX_STAMPS
   if (lane == 0) {
-    unsigned long long *o = g.prof + ((size_t)blockIdx.x * 4 + wave) * 16;
+    unsigned long long *o = g.prof + ((size_t)blockIdx.x * NW + wave) * 16;
     for (int k = 0; k < 8; ++k) o[k] = prof_acc[k];
   }
 #endif
-#undef DK_W1_PRELOAD
 #undef DK_T_ISSUE
 #undef DK_T_COMMIT
 }

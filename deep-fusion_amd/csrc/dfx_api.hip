@@ -57,7 +57,7 @@ DFX_DECL(u8);
 #undef DFX_DECL
 
 #define DFX_DECL(n) \
-  int launch_conv_direct_##n(const ConvArgs &, const DirectGeom &, int, int, int, int, int, hipStream_t, int)
+  int launch_conv_direct_##n(const ConvArgs &, const DirectGeom &, int, int, int, int, int, int, hipStream_t, int)
 DFX_DECL(f32);
 DFX_DECL(s32);
 DFX_DECL(s8);
@@ -96,7 +96,7 @@ static size_t dt_size(int dt) { return (dt == DFX_F32 || dt == DFX_S32) ? 4 : 1;
 namespace {
 const char *const kTuningKeys[] = {"DFX_MAX_TH", "DFX_FORCE_GEOM", "DFX_STATIC_ROUNDS", "DFX_NO_FAST", "DFX_NO_MAGIC", "DFX_NO_LAZY", "DFX_NO_ROLES", "DFX_STORE_BOUND_BYTES",
                                    "DFX_STREAM_PXB", "DFX_STREAM_BLOCKING", "DFX_STREAM_PLANES", "DFX_STREAM_OCC_PAR",
-                                   "DFX_STREAM_SPLIT", "DFX_STREAM_DIRECT", "DFX_STREAM_GRID", "DFX_DEBUG_PTRS",
+                                   "DFX_STREAM_SPLIT", "DFX_STREAM_DIRECT", "DFX_DIRECT_NPB", "DFX_DIRECT_NW", "DFX_DIRECT_WO1", "DFX_STREAM_GRID", "DFX_DEBUG_PTRS",
                                    "DEEPFUSION_PROFILE"};
 struct Tuning {
   std::mutex mu;
@@ -147,7 +147,7 @@ struct dfx_conv {
   MfmaGeom geom;
   StreamGeom sgeom;  // DFX_VARIANT_MFMA_STREAM
   DirectGeom dgeom;  // DFX_VARIANT_MFMA_STREAM served by conv_direct.cuh (fused ops): direct != 0
-  int direct, wo, wo1;
+  int direct, nw, wo, wo1;
   int occ, pxb;      // stream variant: conv0 output blocks per chunk, pixel blocks per wave
   // stream variant, fused op with too few units to fill the machine: run as two unfused
   // launches (3x3 -> u8 intermediate in global memory -> 1x1), each with (unit, chunk) items
@@ -469,8 +469,10 @@ static bool roles_eligible(const dfx_conv_desc &d) {
 }
 
 // ---- direct-weight fused kernel (conv_direct.cuh) ----
-static bool pick_direct_geometry(const dfx_conv_desc &d, int WO, int G, DirectGeom &g, int &lds) {
-  const int M = DK_M;
+static bool pick_direct_geometry(const dfx_conv_desc &d, int NW, int WO, int G, int npb, DirectGeom &g, int &lds) {
+  const int M = 32 * npb;  // pixel slots per unit
+  g.npb = npb;
+  g.m0 = g.m1 = 0;
   const int ocb_real = (d.oc + 31) / 32;
   g.icb = (d.ic + 31) / 32;
   g.n_planes = (g.icb + 1) / 2;
@@ -478,8 +480,8 @@ static bool pick_direct_geometry(const dfx_conv_desc &d, int WO, int G, DirectGe
   g.ocb = (ocb_real + WO - 1) / WO * WO;
   g.n_g1 = ((d.oc1x1 + 31) / 32 + G - 1) / G;
   g.mid_stride = 32 * g.ocb + 16;
-  const size_t cst_bytes = round16((size_t)3 * 32 * g.ocb * 4);
-  const size_t stage_bytes = (G == 4 && dt_size(d.dst_dt) == 1) ? (size_t)4 * DK_STAGE : 0;
+  const size_t cst_bytes = round16((size_t)3 * 32 * (g.ocb + G * g.n_g1) * 4);  // both stages' constants
+  const size_t stage_bytes = (G == 4 && dt_size(d.dst_dt) == 1) ? (size_t)NW * DK_STAGE : 0;
   const size_t fixed = 4 * M + (size_t)M * g.mid_stride + cst_bytes;
   const size_t lds_max = 163840;
   if ((long long)d.bs * d.oh * d.ow * d.oc1x1 * (long long)dt_size(d.dst_dt) >= (1LL << 32) - 16 ||
@@ -523,10 +525,10 @@ static bool pick_direct_geometry(const dfx_conv_desc &d, int WO, int G, DirectGe
 
 static int direct_dispatch(dfx_conv *h, const ConvArgs &a, hipStream_t s, int mode) {
   switch (h->d.dst_dt) {
-    case DFX_F32: return launch_conv_direct_f32(a, h->dgeom, h->wo, h->G, h->wo1, h->grid, h->lds, s, mode);
-    case DFX_S32: return launch_conv_direct_s32(a, h->dgeom, h->wo, h->G, h->wo1, h->grid, h->lds, s, mode);
-    case DFX_S8: return launch_conv_direct_s8(a, h->dgeom, h->wo, h->G, h->wo1, h->grid, h->lds, s, mode);
-    case DFX_U8: return launch_conv_direct_u8(a, h->dgeom, h->wo, h->G, h->wo1, h->grid, h->lds, s, mode);
+    case DFX_F32: return launch_conv_direct_f32(a, h->dgeom, h->nw, h->wo, h->G, h->wo1, h->grid, h->lds, s, mode);
+    case DFX_S32: return launch_conv_direct_s32(a, h->dgeom, h->nw, h->wo, h->G, h->wo1, h->grid, h->lds, s, mode);
+    case DFX_S8: return launch_conv_direct_s8(a, h->dgeom, h->nw, h->wo, h->G, h->wo1, h->grid, h->lds, s, mode);
+    case DFX_U8: return launch_conv_direct_u8(a, h->dgeom, h->nw, h->wo, h->G, h->wo1, h->grid, h->lds, s, mode);
   }
   return -1;
 }
@@ -756,20 +758,59 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
   if (const char *e = tune("DFX_STREAM_DIRECT")) want_direct = stream_ok && d.oc1x1 > 0 && d.oc >= 64 && d.oc1x1 >= 64 && atoi(e) != 0;
   if (want_direct) {
     const int ocb2 = ((d.oc + 31) / 32 + 1) / 2 * 2;
-    h->wo = ocb2 % 4 == 0 ? 4 : 2;
     const int ncb1 = (d.oc1x1 + 31) / 32;
     const int G = ncb1 >= 3 ? 4 : 2;
-    h->wo1 = 1;
-    int lds = 0;
-    if (pick_direct_geometry(d, h->wo, G, h->dgeom, lds)) {
+    // Pixel blocks per unit: the largest of 4, 2, 1 whose units still fill three quarters of the workgroup slots
+    // (two per CU).  Smaller units re-stream the weights more often, larger ones leave CUs (res4: 196 units of
+    // 128 pixels for 512 slots, res5: 64) or SIMDs empty.  With fewer than 4 blocks the four waves split the
+    // output blocks of BOTH stages four ways (WO = WO1 = 4).  DFX_DIRECT_NPB forces one (testing aid).
+    int ncu2 = 512;
+    {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu2 = 2 * prop.multiProcessorCount;
+    }
+    int forced = 0, forced_nw = 0, forced_wo1 = 0;
+    if (const char *e = tune("DFX_DIRECT_NPB")) forced = atoi(e);
+    if (const char *e = tune("DFX_DIRECT_NW")) forced_nw = atoi(e);
+    if (const char *e = tune("DFX_DIRECT_WO1")) forced_wo1 = atoi(e);
+    const int ocb_real = (d.oc + 31) / 32, n_g1 = (ncb1 + G - 1) / G;
+    // candidates in order of preference (instances: conv_direct_inst.inc):
+    //  * four waves, 128-pixel units, where those fill three quarters of the workgroup slots (two per CU);
+    //  * eight waves (one workgroup per CU, two waves per SIMD, each weight byte fetched once or twice per
+    //    unit) with the largest unit that still fills three quarters of the CUs;
+    //  * four waves with smaller units.
+    struct Cand { int nw, wo, wo1, npb, min_units; };
+    std::vector<Cand> cands;
+    const int wo4 = ocb2 % 4 == 0 ? 4 : 2;
+    const int wo1_4 = (G == 4 && wo4 == 4 && n_g1 % 4 == 0) ? 4 : 1;
+    cands.push_back({4, wo4, wo1_4, 4, 3 * ncu2 / 4});
+    if (wo1_4 == 4) cands.push_back({4, wo4, 1, 4, 3 * ncu2 / 4});
+    if (G == 4 && ocb_real % 8 == 0)
+      for (int npb : {4, 2, 1}) cands.push_back({8, 8, 8, npb, npb == 1 ? 0 : 3 * ncu2 / 8});
+    for (int npb : {2, 1}) cands.push_back({4, 4, 4, npb, npb == 1 ? 0 : 3 * ncu2 / 4});
+    for (const Cand &c : cands) {
+      if (forced && c.npb != forced) continue;
+      if (forced_nw && c.nw != forced_nw) continue;
+      if (forced_wo1 && c.wo1 != forced_wo1) continue;
+      DirectGeom dg;
+      memset(&dg, 0, sizeof(dg));
+      int lds = 0;
+      if (!pick_direct_geometry(d, c.nw, c.wo, G, c.npb, dg, lds)) continue;
+      if (!forced && dg.total_units < c.min_units) continue;  // too few units: try the next candidate
+      h->dgeom = dg;
       h->direct = 1;
       h->G = G;
+      h->nw = c.nw;
+      h->wo = c.wo;
+      h->wo1 = c.wo1;
       h->lds = lds;
+      break;
     }
   }
   if (stream_ok && h->direct) {
     h->variant = DFX_VARIANT_MFMA_STREAM;
-    h->block = DK_THREADS;
+    h->block = 64 * h->nw;
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
@@ -786,9 +827,9 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     if (const char *e = tune("DFX_STREAM_GRID")) h->grid = std::max(1, std::min(h->grid, atoi(e)));  // testing aid
     a.rows_per_unit = h->dgeom.thv;
     a.units_per_image = h->dgeom.uy * h->dgeom.ux;
-    snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_direct_kernel<%d,%d,%d,%d>", h->wo, h->G, h->wo1, d.dst_dt);
+    snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_direct_kernel<nw%d,%d,%d,%d,%d,npb%d>", h->nw, h->wo, h->G, h->wo1, d.dst_dt, h->dgeom.npb);
 #ifdef DFX_STAMPS
-    if (hipMalloc((void **)&h->d_prof, (size_t)h->grid * 64 * 8) != hipSuccess || hipMemset(h->d_prof, 0, (size_t)h->grid * 64 * 8) != hipSuccess) {
+    if (hipMalloc((void **)&h->d_prof, (size_t)h->grid * h->nw * 16 * 8) != hipSuccess || hipMemset(h->d_prof, 0, (size_t)h->grid * h->nw * 16 * 8) != hipSuccess) {
       conv_release(h);
       return fail(DFX_ERR_HIP, "conv_create: cannot allocate the stamp buffer");
     }
@@ -1168,6 +1209,72 @@ static int set_weights_direct(dfx_conv_t *h, const int8_t *wei, const void *bia0
       put_f((size_t)3 * OCP + OC1P + c, (float)((double)cst[(size_t)3 * OCP + c] + (double)fb1[c]));
   }
   h->dgeom.fast = fast ? 1 : 0;
+  // Requant without int -> float conversions (conv_direct.cuh, round 3), proven per channel from the actual
+  // weights like the modes of the resident kernels: with activations stored as u8 - 128 the raw accumulator lies
+  // in [-(128 P + 127 N), 127 P + 128 N] (P / N = sums of the positive / negative weights' magnitudes).
+  //   m0  stage 0 "fma": start value bits(2^23) + comp + bias, t = acc + bias inside (-2^23, 2^23), bias
+  //       integer-valued, scale >= 0: comp slot <- start bits, bias slot <- -2^23 * scale
+  //   m1  stage 1 "magic" (u8 output through the 16-byte store path only): start 1/(2 pi), conditions of
+  //       magic1_ok; bias slot <- (comp + bias - 2^23 - 0x22F983) * 2^-26, scale slot <- scale * 2^26 (m1 = 2),
+  //       or bias slot <- (comp + bias - 2^23 - 0x22F983) * scale where that product is exact for every channel:
+  //       one fma (m1 = 3)
+  h->dgeom.m0 = h->dgeom.m1 = 0;
+  const bool no_magic = tune("DFX_NO_MAGIC") && atoi(tune("DFX_NO_MAGIC")) != 0;
+  if (fast && !no_magic) {
+    auto pn = [&](bool stage1, int c, double &P, double &N) {
+      P = N = 0;
+      if (!stage1) {
+        for (int ic = 0; ic < IC; ++ic)
+          for (int tap = 0; tap < ntap; ++tap) {
+            const int w = wei[dfx_blocked_offset(c, ic, tap / d.kw, tap % d.kw, IC, d.kh, d.kw)];
+            (w > 0 ? P : N) += std::abs(w);
+          }
+      } else {
+        for (int oc = 0; oc < OC; ++oc) {
+          const int w = wei1[dfx_blocked_offset(c, oc, 0, 0, OC, 1, 1)];
+          (w > 0 ? P : N) += std::abs(w);
+        }
+      }
+    };
+    bool m0 = true;
+    for (int c = 0; c < OC && m0; ++c) {
+      double P, N;
+      pn(false, c, P, N);
+      const float sc = scales0[d.conv0_nscales > 1 ? c : 0];
+      const double b = fb0[c], cb = 128.0 * (P - N) + b;
+      m0 = b == std::floor(b) && sc >= 0.0f && std::isfinite(sc * 8388608.0f) &&
+           -(128.0 * P + 127.0 * N) + cb > -8388608.0 && 127.0 * P + 128.0 * N + cb < 8388608.0;
+    }
+    if (m0) {
+      for (int c = 0; c < OC; ++c) {
+        const float sc = scales0[d.conv0_nscales > 1 ? c : 0];
+        cst[c] = MAGIC3_BITS + cst[c] + (int32_t)fb0[c];
+        put_f((size_t)OCP + c, -8388608.0f * sc);
+      }
+      h->dgeom.m0 = 1;
+    }
+    bool m1 = d.dst_dt == DFX_U8 && G == 4, fma1 = true;
+    for (int c = 0; c < OC1 && m1; ++c) {
+      double P, N;
+      pn(true, c, P, N);
+      const float sc = scales1[d.conv1_nscales > 1 ? c : 0];
+      const double b = fb1[c], cb = 128.0 * (P - N) + b, lo = -(128.0 * P + 127.0 * N), hi = 127.0 * P + 128.0 * N;
+      const double k = cb - 8388608.0 - (double)0x22F983;
+      m1 = b == std::floor(b) && lo >= (double)MAGIC1_LO && hi <= (double)MAGIC1_HI && std::fabs(k) < 16777216.0 &&
+           std::fabs(lo + cb) < 16777216.0 && std::fabs(hi + cb) < 16777216.0 && std::isfinite(sc * 67108864.0f);
+      const double prod = k * (double)sc;
+      fma1 = fma1 && std::isfinite(prod) && (double)(float)prod == prod;
+    }
+    if (m1) {
+      for (int c = 0; c < OC1; ++c) {
+        const float sc = scales1[d.conv1_nscales > 1 ? c : 0];
+        const double k = (double)cst[(size_t)3 * OCP + c] + (double)fb1[c] - 8388608.0 - (double)0x22F983;
+        put_f((size_t)3 * OCP + OC1P + c, fma1 ? (float)(k * (double)sc) : (float)k * 1.4901161193847656e-08f);
+        put_f((size_t)3 * OCP + 2 * OC1P + c, sc * 67108864.0f);
+      }
+      h->dgeom.m1 = fma1 ? 3 : 2;
+    }
+  }
 #ifdef DK_DEBUG
   h->dgeom.wei_bytes = (long long)n0; h->dgeom.wei1_bytes = (long long)n1; h->dgeom.cst_bytes = (long long)cst.size() * 4;
 #endif
@@ -1554,7 +1661,7 @@ int *dfx_debug_trace(dfx_conv_t *h) { return h ? h->trace_host : nullptr; }
 // diagnostic build only: copies the [grid][8 waves][8] stamp sums of the last launch
 int dfx_debug_read_stamps(dfx_conv_t *h, unsigned long long *out, int max_entries) {
   if (!h || !h->d_prof) return fail(DFX_ERR_STATE, "no stamps");
-  int n = h->grid * (h->variant == DFX_VARIANT_MFMA_STREAM ? (h->direct ? 64 : 96) : 768);
+  int n = h->grid * (h->variant == DFX_VARIANT_MFMA_STREAM ? (h->direct ? h->nw * 16 : 96) : 768);
   if (n > max_entries) n = max_entries;
   HIP_TRY(hipMemcpy(out, h->d_prof, (size_t)n * 8, hipMemcpyDeviceToHost));
   return n;

@@ -24,9 +24,10 @@ torch.cuda.synchronize()
 L = capi.lib()
 L.dfx_debug_read_stamps.restype = ctypes.c_int
 L.dfx_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
-buf = np.zeros(info.grid * 64, dtype=np.uint64)
+nw = info.block // 64
+buf = np.zeros(info.grid * nw * 16, dtype=np.uint64)
 n = L.dfx_debug_read_stamps(op._h, buf.ctypes.data_as(ctypes.c_void_p), buf.size)
-p = buf[:n].reshape(info.grid, 4, 16).astype(np.float64)
+p = buf[:n].reshape(info.grid, nw, 16).astype(np.float64)
 print(wl, desc, "kernel", info.kernel_name.decode(), "grid", info.grid, "lds", info.lds_bytes)
 units = p[..., 7]
 names = ["barrier + tile staging", "conv0 K loop", "requant 0", "barrier after conv0", "conv1 K loop", "requant 1 + stores", "whole unit"]

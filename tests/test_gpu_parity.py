@@ -285,6 +285,39 @@ def test_direct_weight_kernel(hip, oracle, tuning, grid):
             hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), info.kernel_name.decode() + " " + case.ident())
 
 
+@pytest.mark.parametrize("split", ["nw4 wo1=1 npb4", "nw4 wo1=4 npb4", "nw4 wo1=4 npb2", "nw4 wo1=4 npb1",
+                                   "nw8 wo1=8 npb4", "nw8 wo1=8 npb2", "nw8 wo1=8 npb1"])
+@pytest.mark.parametrize("switch", [None, "DFX_NO_MAGIC", "DFX_NO_FAST"])
+def test_direct_weight_kernel_unit_sizes(hip, oracle, tuning, split, switch):
+    """conv_direct.cuh with four or eight waves per workgroup (DFX_DIRECT_NW), the 1x1 stage split by pixel blocks
+    or by channel groups (DFX_DIRECT_WO1) and 1, 2 or 4 pixel blocks per unit (DFX_DIRECT_NPB; the host picks all
+    three by the number of units), and its three requant routes: fma / magic without conversions (default where
+    the host can prove the ranges), fast (DFX_NO_MAGIC), exact (DFX_NO_FAST)."""
+    nw, wo1, npb = split[2], split.split("wo1=")[1][0], split[-1]
+    tuning.setenv("DFX_STREAM_DIRECT", "1")
+    tuning.setenv("DFX_DIRECT_NW", nw)
+    tuning.setenv("DFX_DIRECT_WO1", wo1)
+    tuning.setenv("DFX_DIRECT_NPB", npb)
+    if switch:
+        tuning.setenv(switch, "1")
+    cases = DIRECT_SHAPES + [replace(C.CONFIG3_SMALL, dst_dt=C.U8), replace(C.CONFIG3_SMALL, dst_dt=C.U8, wide=True),
+                             C.ConvCase("d14", 3, 256, 14, 14, 256, 512, dst_dt=C.U8),
+                             C.ConvCase("d7", 5, 128, 7, 7, 192, 384, dst_dt=C.U8, per_channel0=True, per_channel1=True),
+                             C.ConvCase("d7s8", 2, 128, 7, 7, 128, 256, dst_dt=C.S8, relu1=False),
+                             C.ConvCase("d28s32", 1, 64, 28, 28, 128, 128, dst_dt=C.S32)]
+    for case in cases:
+        data = C.generate(case)
+        got, info = hip.hip_conv(case, data, force_variant=hip.dfa.VARIANT_MFMA_STREAM)
+        name = info.kernel_name.decode()
+        if not name.startswith("conv_direct_kernel"):
+            # no instance of this split for the shape (eight waves need a multiple of 8 output blocks and groups
+            # of four; wo1 = 4 needs a multiple of 4 groups): the op falls back to conv_stream.cuh
+            assert nw == "8" or wo1 == "4", name
+        else:
+            assert name.startswith("conv_direct_kernel<nw%s," % nw) and name.endswith("npb%s>" % npb), name
+        hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), name + " " + case.ident())
+
+
 def _random_cases(n, seed, big=False):
     """seeded random shapes inside what the reference's init_conf admits: channels multiples
     of 16, any kernel / stride / padding with a non-empty output"""
