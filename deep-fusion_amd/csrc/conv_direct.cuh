@@ -92,15 +92,21 @@ struct DirectGeom {
 
 // NW waves per workgroup: 4 (two workgroups per CU where the units and the LDS allow) or 8 (one workgroup per CU,
 // two waves per SIMD: layers whose 128-pixel units do not even fill the CUs once)
-template <int NW, int WO, int G, int WO1, int DST, int NPB>
+// QM: requant routes fixed at compile time.  0: both stages choose exact / fast (/ stage-0 fma) at run time;
+// 1 / 2 (u8 output through the 16-byte store path): stage 0 "fma", stage 1 "magic" / "fma" -- with the four
+// routes of the store epilogue as run-time branches hipcc copied every accumulator out of its MFMA tuple at the
+// head of the taken branch (64 v_mov per 32 x 128 block and twice the registers: 256 VGPRs and spills).
+template <int NW, int WO, int G, int WO1, int DST, int NPB, int QM>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(ConvArgs a, DirectGeom g) {
+  static_assert(QM == 0 || (DST == DFX_U8 && G == 4), "the conversion-free routes exist for u8 output with G = 4");
   constexpr int DK_THREADS = 64 * NW;
   constexpr int ESZ = (DST == DFX_F32 || DST == DFX_S32) ? 4 : 1;
   constexpr int WP = NW / WO, PXW = NPB / WP;        // conv0: WO x WP waves, PXW pixel blocks per wave
   constexpr int WP1 = NW / WO1, PXW1 = NPB / WP1;    // conv1 likewise
   static_assert(WO * WP == NW && WO1 * WP1 == NW && WP * PXW == NPB && WP1 * PXW1 == NPB && PXW >= 1 && PXW1 >= 1,
                 "wave split must tile the unit's pixel blocks");
-  constexpr int PX1 = G == 4 ? 1 : (PXW1 > 2 ? 2 : PXW1);  // pixel blocks per conv1 pass (accumulators: PX1 * G * 16 VGPRs; with 128 hipcc spills whole accumulators around the epilogue's mode branches)
+  // pixel blocks per conv1 pass (accumulators: PX1 * G * 16 VGPRs)
+  constexpr int PX1 = G == 4 ? ((QM != 0 && PXW1 >= 2) ? 2 : 1) : (PXW1 > 2 ? 2 : PXW1);
   constexpr int NP1 = PXW1 / PX1;             // conv1 passes per group
   // conv1 weight ring depth in k-blocks (G fragments each).  Even, and it divides ocb (a multiple of WO): the
   // ring never has to stop at the end of a group.
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
           DK_LOAD_FB(1);
         }
         v16i acc[PXW];
-        if (g.m0) {  // "fma": start from bits(2^23) + comp + bias of this lane's 16 channels (comp slot of the constants)
+        if (QM != 0 || g.m0) {  // "fma": start from bits(2^23) + comp + bias of this lane's 16 channels (comp slot of the constants)
           v16i st;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -377,9 +383,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
           }
         }
         DFX_STAMP(t2);
-        if (g.m0) requant0(std::integral_constant<int, 2>{}, ob, acc);
-        else if (fast) requant0(std::integral_constant<int, 1>{}, ob, acc);
-        else requant0(std::integral_constant<int, 0>{}, ob, acc);
+        if constexpr (QM != 0) {
+          requant0(std::integral_constant<int, 2>{}, ob, acc);
+        } else {
+          if (g.m0) requant0(std::integral_constant<int, 2>{}, ob, acc);
+          else if (fast) requant0(std::integral_constant<int, 1>{}, ob, acc);
+          else requant0(std::integral_constant<int, 0>{}, ob, acc);
+        }
         DFX_STAMP(t3);
         DFX_ACC(2, t3 - t2);  // requant 0
         DFX_ACC(1, t2 - t1b);  // conv0 K loop
@@ -439,7 +449,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
           }
           v16i acc1[PX1][G];
           {
-            const int m1s = g.m1 ? MAGIC1_BITS : 0;  // "magic": the accumulator's bits read as 1/(2 pi) + raw * 2^-26
+            const int m1s = QM != 0 ? MAGIC1_BITS : 0;  // "magic": the accumulator's bits read as 1/(2 pi) + raw * 2^-26
             const v16i st1 = {m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s};
 #pragma unroll
             for (int p = 0; p < PX1; ++p)
@@ -518,14 +528,24 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
                   }
                   *reinterpret_cast<unsigned *>(stg + (8 * (e >> 2) + (e & 3) + 4 * h) * 144 + 4 * l31) = pk;
                 }
+                // all eight LDS reads first (one wait), then the stores: inside the stores' exec-masked regions
+                // hipcc issued them one by one, two dependent LDS round trips per store
+                unsigned off4[4];
+                v4i val4[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                   const int c = lane + 64 * k, px = c >> 3, c16 = c & 7;
-                  const unsigned off = pxoff[32 * (pb0 + p) + px];
-                  const v4i val = *reinterpret_cast<const v4i *>(stg + px * 144 + 16 * c16);
-                  if (off != 0xffffffffu && 128 * g1 + 16 * c16 < a.oc1)
-                    DFX_STORE16(reinterpret_cast<v4i *>(dst_b + DK_CHK(11, (long long)(off + 128 * g1 + 16 * c16), 16, g.dst_bytes)), val);
+                  off4[k] = pxoff[32 * (pb0 + p) + px];
+                  val4[k] = *reinterpret_cast<const v4i *>(stg + px * 144 + 16 * c16);
                 }
+                DKF();
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  const int c16 = lane & 7;
+                  if (off4[k] != 0xffffffffu && 128 * g1 + 16 * c16 < a.oc1)
+                    DFX_STORE16(reinterpret_cast<v4i *>(dst_b + DK_CHK(11, (long long)(off4[k] + 128 * g1 + 16 * c16), 16, g.dst_bytes)), val4[k]);
+                }
+                DKF();
               }
             } else {
               if (chb < a.oc1) {
@@ -549,10 +569,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
               }
             }
           };
-          if (DST == DFX_U8 && G == 4 && g.m1 == 3) emit(std::integral_constant<int, 3>{});
-          else if (DST == DFX_U8 && G == 4 && g.m1 == 2) emit(std::integral_constant<int, 2>{});
-          else if (fast) emit(std::integral_constant<int, 1>{});
-          else emit(std::integral_constant<int, 0>{});
+          if constexpr (QM == 2) {
+            emit(std::integral_constant<int, 3>{});
+          } else if constexpr (QM == 1) {
+            emit(std::integral_constant<int, 2>{});
+          } else {
+            if (fast) emit(std::integral_constant<int, 1>{});
+            else emit(std::integral_constant<int, 0>{});
+          }
           DFX_STAMP(t8);
           DFX_ACC(5, t8 - t7);  // requant 1 + stores
         }

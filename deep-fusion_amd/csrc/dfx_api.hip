@@ -1265,6 +1265,7 @@ static int set_weights_direct(dfx_conv_t *h, const int8_t *wei, const void *bia0
       const double prod = k * (double)sc;
       fma1 = fma1 && std::isfinite(prod) && (double)(float)prod == prod;
     }
+    m1 = m1 && m0;  // (the kernels specialise on "both stages without conversions": conv_direct.cuh, QM)
     if (m1) {
       for (int c = 0; c < OC1; ++c) {
         const float sc = scales1[d.conv1_nscales > 1 ? c : 0];
