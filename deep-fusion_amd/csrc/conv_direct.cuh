@@ -44,7 +44,7 @@ namespace dfx {
 
 constexpr int DK_M = 128;    // pixel slots per unit at most (NPB = 4 blocks of 32)
 constexpr int DK_POS = 80;   // LDS bytes per halo-tile position and plane (64 + 16 pad)
-constexpr int DK_TQ = 4;     // tile granules a thread prefetches into registers
+constexpr int DK_TQ = 6;     // tile granules a thread holds in registers at once (4 waves: 24 KB of tile, 8 waves: 48 KB)
 constexpr int DK_RD = 9;     // conv0 weight ring: k-blocks in flight per wave (multiple of 3)
 constexpr int DK_STAGE = 32 * 144;  // per wave: 1-byte store staging (aliases the dead tile)
 
@@ -113,6 +113,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
   constexpr int RD1 = (WO % 4 != 0 || PX1 * G > 4) ? 2 : 4;
   static_assert(WO % RD1 == 0, "the conv1 ring must divide the number of output blocks");
   constexpr int NF = PXW < 2 ? PXW : 2;       // MFMAs issued before the k-block's LDS prefetch
+  DFX_STAMP(t_entry);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *const tile0 = smem;
   unsigned *pxoff = reinterpret_cast<unsigned *>(smem + g.off_pxoff);
@@ -137,17 +138,43 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
   using TT = std::true_type;
   using FF = std::false_type;
 
+  // Both stages' constants -> LDS by LDS-DMA (a wave moves 1 KB per instruction; no registers, nothing to wait for
+  // here): they land while the first unit's tile is being staged (vector memory operations complete in order, and
+  // the first unit's second barrier is preceded by s_waitcnt vmcnt(0)).  Through registers this copy cost 3-5 k
+  // cycles at kernel entry (6-9 k from entry to the first unit: profiles/r03/stamps_direct_7_startup.txt).
+  {
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void global_void;
+    const int total16 = 3 * (OCP + OC1P) / 4;  // 16-byte chunks (OCP, OC1P: multiples of 32)
+    const v4i *cs = reinterpret_cast<const v4i *>(a.consts);
+    v4i *cd = reinterpret_cast<v4i *>(cst0);
+    for (int j = wave; 64 * j < total16; j += NW) {
+      const int q = 64 * j + lane;
+      if (q < total16) __builtin_amdgcn_global_load_lds((global_void *)(cs + q), (lds_void *)(cd + 64 * j), 16, 0, 0);
+    }
+  }
   // ---- tile staging: granule q = tid + 256 i -> plane q / (4 npos), position, 16-byte chunk q & 3 ----
   const int lhw = g.lh * g.lw;
   const int row_skip = (g.lw - a.kw) * DK_POS;  // bytes from the last tap of a kernel row to the next row's first
   const int tile_q1 = g.npos * 4, tile_q = tile_q1 * g.n_planes;
   int tq_pos[DK_TQ];  // plane << 28 | img << 20 | ly << 10 | lx
+  // (quotients through f32 reciprocals with a +-1 fix-up: every dividend is < 2^22; the integer division sequence
+  // is ~35 instructions and there are 3 per entry, all on the path from kernel entry to the first tile load)
+  auto divmod = [](int x, int d, float rd, int &rem) -> int {
+    int q = (int)(__int2float_rn(x) * rd);
+    rem = x - q * d;
+    if (rem < 0) { --q; rem += d; }
+    if (rem >= d) { ++q; rem -= d; }
+    return q;
+  };
+  const float r_tq1 = 1.0f / __int2float_rn(tile_q1), r_lhw = 1.0f / __int2float_rn(lhw), r_lw = 1.0f / __int2float_rn(g.lw);
 #pragma unroll
   for (int i = 0; i < DK_TQ; ++i) {
     const int q = min(tid + DK_THREADS * i, tile_q - 1);
-    const int pl = q / tile_q1, pos = (q - pl * tile_q1) >> 2;
-    const int img = pos / lhw, r = pos - img * lhw;
-    const int ly = r / g.lw, lx = r - ly * g.lw;
+    int ql, r, lx;
+    const int pl = divmod(q, tile_q1, r_tq1, ql);
+    const int img = divmod(ql >> 2, lhw, r_lhw, r);
+    const int ly = divmod(r, g.lw, r_lw, lx);
     tq_pos[i] = (pl << 28) | (img << 20) | (ly << 10) | lx;
   }
   const v4i x80 = v4i{(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
@@ -188,6 +215,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
   // spilled them (70-84 VGPRs, ~20 k cycles of scratch reloads per unit).
   const __amdgpu_buffer_rsrc_t w0rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(a.wei), 0, g.ocb * nkb0 * 1024, 0x00020000);
   const __amdgpu_buffer_rsrc_t w1rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(a.wei1), 0, g.n_g1 * g.ocb * G * 1024, 0x00020000);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const int ob_last = wo + (g.ocb - 1 - wo) / WO * WO;
   const int upg = g.uy * g.ux;
   struct UnitGeo { int n0, y0, x0, nimg, iy0, ix0; };
   auto unit_geo = [&](int unit) {
@@ -200,10 +229,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
     return r;
   };
 
-  for (int q = tid; q < 3 * (OCP + OC1P); q += DK_THREADS)  // visible after the first barrier
-    cst0[q] = a.consts[DK_CHK(3, (long long)q * 4, 4, g.cst_bytes) / 4];
+  bool first_unit = true;
 #ifdef DFX_STAMPS
-  unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  bool prof_first = true;
 #endif
 
   for (int unit = blockIdx.x; unit < g.total_units; unit += gridDim.x) {
@@ -215,8 +244,26 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
     const int thc = min(g.thv, a.oh - ug.y0), twc = min(g.twv, a.ow - ug.x0);
     const int npx = ug.nimg * thc * twc;
     DFX_STAMP(t0);
+#ifdef DFX_STAMPS
+    if (prof_first) { prof_acc[8] = t0 - t_entry; prof_first = false; }  // kernel entry -> first unit
+#endif
     // every wave is out of the previous unit (its store staging aliases the tile; pxoff, mid)
     __syncthreads();
+    // the conv0 weight ring (see below).  (Priming it here, before the tile is staged, bought nothing: +-2 %,
+    // profiles/r03/ab_direct_early_prime.txt, for 30 more live VGPRs.)
+    int r_ob = wo, r_kb = 0;  // next block the ring fetches
+    auto r_next = [&]() -> unsigned {  // its index in W0d, then advance (past the stream's end: the last output block again)
+      const unsigned idx = (unsigned)(min(r_ob, ob_last) * nkb0 + r_kb);
+      const bool wrap = r_kb + 1 == nkb0;
+      r_kb = wrap ? 0 : r_kb + 1;
+      r_ob = wrap ? r_ob + WO : r_ob;
+      return idx;
+    };
+    auto wload = [&](unsigned idx) -> v4i {  // buffer_load_dwordx4 v, lane16, rsrc, soffset: no per-lane 64-bit addresses
+      return __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(w0rs, (int)lane16, (int)(idx << 10), 0));
+    };
+    v4i wr[DK_RD];
+    const bool even0 = nkb0 % DK_RD == 0;
     // ---- stage the whole halo tile (all planes) ----
     DK_T_ISSUE(ug.n0, ug.iy0, ug.ix0, ug.nimg);
     if (wave < NPB) {  // slot table: wave w fills pixel block w
@@ -240,6 +287,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
       const long long o = (((long long)n_ * a.ih + y_) * a.iw + x_) * a.ic + min(64 * pl + 16 * j, a.ic - 16);
       const v4i v = *reinterpret_cast<const v4i *>(a.src + DK_CHK(2, o, 16, g.src_bytes));
       *reinterpret_cast<v4i *>(tile0 + pl * g.plane_bytes + pos * DK_POS + 16 * j) = ok ? v ^ x80 : x80;
+    }
+    if (first_unit) {  // the constants' LDS-DMA (see above)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      first_unit = false;
     }
     __syncthreads();
 
@@ -298,22 +349,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
     // the ring was drained every 9 k-blocks, 85 cycles per MFMA at res4).  EVEN (nkb0 a multiple of DK_RD, every
     // 3x3 layer): refills run on into the next output block, the requant of one block hides under the loads of
     // the next.  Otherwise whole rounds are branch-free and the last k-blocks of a block run unpipelined.
-    const unsigned lane16 = (unsigned)lane * 16u;
-    const int ob_last = wo + (g.ocb - 1 - wo) / WO * WO;
     auto conv0_stage = [&](auto even_tag) {
       constexpr bool EVEN = decltype(even_tag)::value;
-      int r_ob = wo, r_kb = 0;  // next block the ring fetches
-      auto r_next = [&]() -> unsigned {  // its index in W0d, then advance (past the stream's end: the last output block again)
-        const unsigned idx = (unsigned)(min(r_ob, ob_last) * nkb0 + r_kb);
-        const bool wrap = r_kb + 1 == nkb0;
-        r_kb = wrap ? 0 : r_kb + 1;
-        r_ob = wrap ? r_ob + WO : r_ob;
-        return idx;
-      };
-      auto wload = [&](unsigned idx) -> v4i {  // buffer_load_dwordx4 v, lane16, rsrc, soffset: no per-lane 64-bit addresses
-        return __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(w0rs, (int)lane16, (int)(idx << 10), 0));
-      };
-      v4i wr[DK_RD];
       int l_tap = 0, l_tkw = 0, l_toff = 0, l_icb = 0;  // position of the NEXT k-block whose pixel fragments get loaded (runs two ahead)
       v4i fb[3][PXW];
 #define DK_LOAD_FB(SET)                                                                 \
@@ -396,7 +433,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
       }
 #undef DK_LOAD_FB
     };
-    if (nkb0 % DK_RD == 0) conv0_stage(TT{}); else conv0_stage(FF{});
+    if (even0) conv0_stage(TT{}); else conv0_stage(FF{});
 
     // ---- conv1: this wave's groups x its PXW1 pixel blocks, PX1 at a time ----
     // Same scheme: the W1 fragments of this wave are one stream of blocks of G fragments (groups wo1, wo1 + WO1,
@@ -584,12 +621,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
     }
     DFX_STAMP(t9);
     DFX_ACC(6, t9 - t0);
+#ifdef DFX_STAMPS
+    prof_acc[9] = t9 - t_entry;  // kernel entry -> end of this wave's (so far) last unit
+#endif
     DFX_ACC(7, 1);
   }
 #ifdef DFX_STAMPS
   if (lane == 0) {
     unsigned long long *o = g.prof + ((size_t)blockIdx.x * NW + wave) * 16;
-    for (int k = 0; k < 8; ++k) o[k] = prof_acc[k];
+    for (int k = 0; k < 10; ++k) o[k] = prof_acc[k];
   }
 #endif
 #undef DK_T_ISSUE

@@ -96,7 +96,7 @@ static size_t dt_size(int dt) { return (dt == DFX_F32 || dt == DFX_S32) ? 4 : 1;
 namespace {
 const char *const kTuningKeys[] = {"DFX_MAX_TH", "DFX_FORCE_GEOM", "DFX_STATIC_ROUNDS", "DFX_NO_FAST", "DFX_NO_MAGIC", "DFX_NO_LAZY", "DFX_NO_ROLES", "DFX_STORE_BOUND_BYTES",
                                    "DFX_STREAM_PXB", "DFX_STREAM_BLOCKING", "DFX_STREAM_PLANES", "DFX_STREAM_OCC_PAR",
-                                   "DFX_STREAM_SPLIT", "DFX_STREAM_DIRECT", "DFX_DIRECT_NPB", "DFX_DIRECT_NW", "DFX_DIRECT_WO1", "DFX_STREAM_GRID", "DFX_DEBUG_PTRS",
+                                   "DFX_STREAM_DIRECT", "DFX_DIRECT_NPB", "DFX_DIRECT_NW", "DFX_DIRECT_WO1", "DFX_STREAM_GRID", "DFX_DEBUG_PTRS",
                                    "DEEPFUSION_PROFILE"};
 struct Tuning {
   std::mutex mu;
@@ -149,14 +149,6 @@ struct dfx_conv {
   DirectGeom dgeom;  // DFX_VARIANT_MFMA_STREAM served by conv_direct.cuh (fused ops): direct != 0
   int direct, nw, wo, wo1;
   int occ, pxb;      // stream variant: conv0 output blocks per chunk, pixel blocks per wave
-  // stream variant, fused op with too few units to fill the machine: run as two unfused
-  // launches (3x3 -> u8 intermediate in global memory -> 1x1), each with (unit, chunk) items
-  dfx_conv *split0, *split1;
-  void *d_mid;
-  hipEvent_t split_done;   // split ops: recorded behind the second launch; the next submit's first launch waits
-  hipStream_t split_last;  // for it when it runs on another stream (the two launches share d_mid)
-  bool split_recorded;     // a previous submit exists (split_last may legitimately be the NULL stream)
-  std::mutex *split_mu;    // split ops: orders concurrent submits from several host threads
   int icb, ocb, G, grid, block, lds;
   // role-specialised fused kernel (conv_mfma_roles.cuh): roles_ok = the SHAPE fits it (decided at create; LDS is
   // then sized for its larger control block), roles = the WEIGHTS allow its requant modes (decided by
@@ -667,14 +659,9 @@ static void conv_release(dfx_conv *h) {
   (void)hipFree(h->d_wei); (void)hipFree(h->d_wei1); (void)hipFree(h->d_consts);
   (void)hipFree(h->d_src); (void)hipFree(h->d_dst); (void)hipFree(h->d_queue);
   (void)hipFree(h->d_prof);
-  (void)hipFree(h->d_mid);
-  if (h->split_done) (void)hipEventDestroy(h->split_done);
-  delete h->split_mu;
   for (unsigned i = 0; i < DFX_QUEUE_RING; ++i)
     if (h->slot_ev[i]) (void)hipEventDestroy(h->slot_ev[i]);
   delete h->ring_mu;
-  conv_release(h->split0);
-  conv_release(h->split1);
   delete h;
 }
 
@@ -747,14 +734,10 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
       return fail(DFX_ERR_UNSUPPORTED, "conv_create: shape does not fit the streamed MFMA variant");
     }
   }
-  // The direct-weight kernel (conv_direct.cuh) serves fused ops with >= 64 channels on both
-  // sides.  Measured against conv_stream.cuh (N=128, u8 out): it wins where the first
-  // contraction is deep (res4-style 256 input channels: 58 vs 65 us), ties at 128 (60 vs 58)
-  // and loses where its whole-tile staging drops LDS occupancy (stride 2) or where too few
-  // units exist and conv_stream's split execution applies -- so: ic >= 256 and enough units.
-  // DFX_STREAM_DIRECT=1/0 forces it on (wherever it fits) / off.
-  bool want_direct = stream_ok && d.oc1x1 > 0 && d.oc >= 64 && d.oc1x1 >= 64 && d.ic >= 256 &&
-                     4 * h->sgeom.total_units > 2 * 256;
+  // The direct-weight kernel (conv_direct.cuh) serves fused ops with >= 64 channels on both sides wherever one of
+  // its instances fits (N=128, u8 out, against conv_stream.cuh: res3 37 vs 50 us, res4 31 vs 53, res5 43 vs 79
+  // in two launches, res3s2 45 vs 63: profiles/r03/direct_sweep_*.txt).  DFX_STREAM_DIRECT=0 turns it off.
+  bool want_direct = stream_ok && d.oc1x1 > 0 && d.oc >= 64 && d.oc1x1 >= 64;
   if (const char *e = tune("DFX_STREAM_DIRECT")) want_direct = stream_ok && d.oc1x1 > 0 && d.oc >= 64 && d.oc1x1 >= 64 && atoi(e) != 0;
   if (want_direct) {
     const int ocb2 = ((d.oc + 31) / 32 + 1) / 2 * 2;
@@ -789,24 +772,28 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     if (G == 4 && ocb_real % 8 == 0)
       for (int npb : {4, 2, 1}) cands.push_back({8, 8, 8, npb, npb == 1 ? 0 : 3 * ncu2 / 8});
     for (int npb : {2, 1}) cands.push_back({4, 4, 4, npb, npb == 1 ? 0 : 3 * ncu2 / 4});
-    for (const Cand &c : cands) {
-      if (forced && c.npb != forced) continue;
-      if (forced_nw && c.nw != forced_nw) continue;
-      if (forced_wo1 && c.wo1 != forced_wo1) continue;
-      DirectGeom dg;
-      memset(&dg, 0, sizeof(dg));
-      int lds = 0;
-      if (!pick_direct_geometry(d, c.nw, c.wo, G, c.npb, dg, lds)) continue;
-      if (!forced && dg.total_units < c.min_units) continue;  // too few units: try the next candidate
-      h->dgeom = dg;
-      h->direct = 1;
-      h->G = G;
-      h->nw = c.nw;
-      h->wo = c.wo;
-      h->wo1 = c.wo1;
-      h->lds = lds;
-      break;
-    }
+    // first pass: four-wave candidates must also leave room for two workgroups per CU (80 KB of LDS each; a
+    // stride-2 layer's 128-pixel halo tile does not: res3s2 72 us with 128-pixel units, 45 us with 64)
+    for (int pass = 0; pass < 2 && !h->direct; ++pass)
+      for (const Cand &c : cands) {
+        if (forced && c.npb != forced) continue;
+        if (forced_nw && c.nw != forced_nw) continue;
+        if (forced_wo1 && c.wo1 != forced_wo1) continue;
+        DirectGeom dg;
+        memset(&dg, 0, sizeof(dg));
+        int lds = 0;
+        if (!pick_direct_geometry(d, c.nw, c.wo, G, c.npb, dg, lds)) continue;
+        if (!forced && dg.total_units < c.min_units) continue;  // too few units: try the next candidate
+        if (!forced && pass == 0 && c.nw == 4 && lds > 81920) continue;
+        h->dgeom = dg;
+        h->direct = 1;
+        h->G = G;
+        h->nw = c.nw;
+        h->wo = c.wo;
+        h->wo1 = c.wo1;
+        h->lds = lds;
+        break;
+      }
   }
   if (stream_ok && h->direct) {
     h->variant = DFX_VARIANT_MFMA_STREAM;
@@ -873,33 +860,8 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
       h->sgeom.occ_par = 1;
     }
     h->grid = std::min(h->sgeom.total_units * (h->sgeom.occ_par ? h->sgeom.n_occ : 1), capacity);
-    // fused op that cannot fill the machine with units: split (see struct dfx_conv)
-    // (measured: res5-style 64 units 199 -> 91 us; res4-style 196 units 64 -> 96 us, so only
-    // below a quarter of the machine)
-    bool split = d.oc1x1 > 0 && 4 * h->sgeom.total_units <= capacity &&
-                 ((d.oc + 127) / 128 > 1 || (d.oc1x1 + 127) / 128 > 1);
-    if (const char *e = tune("DFX_STREAM_SPLIT")) split = d.oc1x1 > 0 && atoi(e) != 0;  // testing aid
-    if (split) {
-      dfx_conv_desc d0 = d, d1 = d;
-      d0.oc1x1 = 0; d0.dst_dt = DFX_U8; d0.bia1_dt = DFX_UNDEF; d0.conv1_nscales = 1;
-      d0.force_variant = DFX_VARIANT_MFMA_STREAM;
-      d1.ic = d.oc; d1.ih = d.oh; d1.iw = d.ow; d1.oc = d.oc1x1; d1.kh = d1.kw = 1; d1.sh = d1.sw = 1;
-      d1.pad_t = d1.pad_l = 0; d1.oc1x1 = 0; d1.bia0_dt = d.bia1_dt; d1.bia1_dt = DFX_UNDEF;
-      d1.conv0_relu = d.conv1_relu; d1.conv0_round_mode = d.conv1_round_mode; d1.conv0_nscales = d.conv1_nscales;
-      d1.conv1_nscales = 1; d1.force_variant = DFX_VARIANT_MFMA_STREAM;
-      if (dfx_conv_create(&d0, &h->split0) != DFX_OK || dfx_conv_create(&d1, &h->split1) != DFX_OK ||
-          hipMalloc(&h->d_mid, (size_t)d.bs * d.oh * d.ow * d.oc) != hipSuccess) {
-        conv_release(h->split0); conv_release(h->split1);
-        (void)hipFree(h->d_mid);
-        h->split0 = h->split1 = nullptr; h->d_mid = nullptr;  // fall back to the single fused launch
-      } else {
-        h->split_mu = new (std::nothrow) std::mutex();
-        if (!h->split_mu || hipEventCreateWithFlags(&h->split_done, hipEventDisableTiming) != hipSuccess) {
-          conv_release(h);
-          return fail(DFX_ERR_HIP, "conv_create: cannot create the split op's ordering event");
-        }
-      }
-    }
+    // (Until round 3 a fused op with too few units to fill the machine ran as two launches through an
+    // intermediate in global memory; conv_direct.cuh's one-launch kernel replaced that path: res5 79 -> 43 us.)
     if (const char *e = tune("DFX_STREAM_GRID")) h->grid = std::max(1, std::min(h->grid, atoi(e)));  // testing aid
 #ifdef DFX_STAMPS
     if (hipMalloc((void **)&h->d_prof, (size_t)h->grid * 96 * 8) != hipSuccess ||
@@ -911,12 +873,8 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
 #endif
     a.rows_per_unit = h->sgeom.thv;
     a.units_per_image = h->sgeom.uy * h->sgeom.ux;
-    if (h->split0)
-      snprintf(h->kernel_name, sizeof(h->kernel_name), "split: conv_stream<%d,%d,u8> %d items + conv_stream<%d,%d,%d> %d items",
-               h->split0->occ, h->split0->pxb, h->split0->grid, h->split1->occ, h->split1->pxb, d.dst_dt, h->split1->grid);
-    else
-      snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_stream_kernel<%d,%d,%d,%d,%s%s>", h->occ, h->G, h->pxb,
-               d.dst_dt, d.oc1x1 ? "fused" : "unfused", h->sgeom.occ_par ? ",occ_par" : "");
+    snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_stream_kernel<%d,%d,%d,%d,%s%s>", h->occ, h->G, h->pxb,
+             d.dst_dt, d.oc1x1 ? "fused" : "unfused", h->sgeom.occ_par ? ",occ_par" : "");
   } else if (d.fuse_pool && !(want_mfma && pick_geometry(d, h->geom, h->lds))) {
     conv_release(h);  // (no other kernel knows about the pooled destination)
     return fail(DFX_ERR_UNSUPPORTED, "conv_create: no unit geometry of the resident-weight kernel fits fused pooling here");
@@ -1318,12 +1276,6 @@ int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei, const void *bia0, con
     s1[c] = scales1[d.conv1_nscales > 1 ? c : 0];
   }
 
-  if (h->split0) {  // the two halves of a split fused op take their own weights
-    int rc = dfx_conv_set_weights(h->split0, wei, bia0, scales0, nullptr, nullptr, nullptr);
-    if (rc == DFX_OK) rc = dfx_conv_set_weights(h->split1, wei1, bia1, scales1, nullptr, nullptr, nullptr);
-    h->weights_set = rc == DFX_OK;
-    return rc;
-  }
   if (h->variant == DFX_VARIANT_MFMA_STREAM) return set_weights_stream(h, wei, bia0, scales0, wei1, bia1, scales1);
 
   if (h->variant != DFX_VARIANT_GENERIC) {
@@ -1542,20 +1494,6 @@ int dfx_conv_submit(dfx_conv_t *h, const void *src_dev, void *dst_dev, dfx_strea
   if (!h || !src_dev || !dst_dev) return fail(DFX_ERR_INVALID, "conv_submit: null argument");
   if (!h->weights_set) return fail(DFX_ERR_STATE, "conv_submit: dfx_conv_set_weights not called");
   DeviceGuard dg(h->device);
-  if (h->split0) {
-    // The two launches share the intermediate d_mid: submits of a split op are ordered among each
-    // other, whatever streams they come on -- the first launch of a submit waits (on the device) for
-    // the second launch of the previous one.  Other work on those streams is not held up.
-    std::lock_guard<std::mutex> lk(*h->split_mu);
-    if (h->split_recorded && h->split_last != (hipStream_t)s) HIP_TRY(hipStreamWaitEvent((hipStream_t)s, h->split_done, 0));
-    int rc0 = dfx_conv_submit(h->split0, src_dev, h->d_mid, s);
-    if (rc0 == DFX_OK) rc0 = dfx_conv_submit(h->split1, h->d_mid, dst_dev, s);
-    if (rc0 != DFX_OK) return rc0;
-    HIP_TRY(hipEventRecord(h->split_done, (hipStream_t)s));
-    h->split_last = (hipStream_t)s;
-    h->split_recorded = true;
-    return DFX_OK;
-  }
   // per-launch copies: concurrent submits of one handle (other host threads, other streams) share
   // only immutable state and each takes its own unit-queue slot of the ring
   ConvArgs a = h->args;

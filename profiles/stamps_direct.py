@@ -33,3 +33,5 @@ units = p[..., 7]
 names = ["barrier + tile staging", "conv0 K loop", "requant 0", "barrier after conv0", "conv1 K loop", "requant 1 + stores", "whole unit"]
 for k, nm in enumerate(names):
     print("%-28s %10.0f cycles/unit/wave %6.1f%%" % (nm, p[..., k].sum() / units.sum(), 100 * p[..., k].sum() / p[..., 6].sum()))
+print("%-28s %10.0f cycles (mean over waves)" % ("entry -> first unit", p[..., 8].mean()))
+print("%-28s %10.0f cycles (mean over waves that had units) max %.0f" % ("entry -> wave done", p[..., 9][p[..., 7] > 0].mean(), p[..., 9].max()))

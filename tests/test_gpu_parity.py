@@ -170,16 +170,25 @@ STREAM_CASES = (STREAM_SHAPES + C.dtype_matrix(C.SMALL) + C.option_sweep(C.SMALL
 
 
 @pytest.mark.parametrize("case", STREAM_CASES, ids=lambda c: c.ident())
-def test_stream_variant(hip, oracle, case):
+def test_stream_variant(hip, oracle, tuning, case):
+    """the general-shape variant as the host picks it; where that is conv_direct.cuh (fused, >= 64 channels on both
+    sides) also conv_stream.cuh's fused path, which stays the fallback for shapes no direct instance fits"""
     data = C.generate(case)
+    ref = hip.oracle_conv(oracle, case, data)
     got, info = hip.hip_conv(case, data, force_variant=hip.dfa.VARIANT_MFMA_STREAM)
     assert info.variant == hip.dfa.VARIANT_MFMA_STREAM, info.kernel_name
-    hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), info.kernel_name.decode())
+    hip.assert_bit_equal(got, ref, info.kernel_name.decode())
+    if info.kernel_name.decode().startswith("conv_direct_kernel"):
+        tuning.setenv("DFX_STREAM_DIRECT", "0")
+        got, info = hip.hip_conv(case, data, force_variant=hip.dfa.VARIANT_MFMA_STREAM)
+        assert info.kernel_name.decode().startswith("conv_stream_kernel"), info.kernel_name
+        hip.assert_bit_equal(got, ref, info.kernel_name.decode())
 
 
 def test_stream_variant_exact_requant_path(hip, oracle, tuning):
     """DFX_NO_FAST=1 (read at set_weights) forces the exact requant code path on inputs the
     fast-path proof would otherwise accept."""
+    tuning.setenv("DFX_STREAM_DIRECT", "0")   # conv_stream.cuh is the subject here (conv_direct.cuh: tests below)
     tuning.setenv("DFX_NO_FAST", "1")
     for case in STREAM_SHAPES[:12] + C.dtype_matrix(C.SMALL) + [C.unfused(c) for c in C.dtype_matrix(C.SMALL)]:
         data = C.generate(case)
@@ -191,6 +200,7 @@ def test_stream_variant_exact_requant_path(hip, oracle, tuning):
 def test_stream_variant_many_units_per_workgroup(hip, oracle, tuning, grid):
     """DFX_STREAM_GRID caps the grid so that every workgroup walks many units: covers the
     cross-unit tile / weight prefetch and the unit-to-unit LDS reuse."""
+    tuning.setenv("DFX_STREAM_DIRECT", "0")   # conv_stream.cuh is the subject here (conv_direct.cuh: tests below)
     tuning.setenv("DFX_STREAM_GRID", grid)
     for case in STREAM_SHAPES + [C.CONFIG3_SMALL, C.unfused(C.CONFIG2), replace(C.CONFIG3_SMALL, dst_dt=C.U8, wide=True)]:
         data = C.generate(case)
@@ -211,7 +221,8 @@ STREAM_FULL = [
 
 @pytest.mark.parametrize("case", STREAM_FULL, ids=lambda c: c.ident())
 def test_stream_variant_full_size(hip, oracle, case):
-    """ResNet-50 res3..res5-style blocks at (near) bench size: more units than workgroups."""
+    """ResNet-50 res3..res5-style blocks at (near) bench size: more units than workgroups (fused: conv_direct.cuh
+    with the host's choice of waves, unit size and 1x1 split; unfused: conv_stream.cuh)."""
     data = C.generate(case)
     got, info = hip.hip_conv(case, data)
     assert info.variant == hip.dfa.VARIANT_MFMA_STREAM, info.kernel_name
@@ -222,6 +233,7 @@ def test_stream_variant_full_size(hip, oracle, case):
 def test_stream_variant_resident_input_chunks(hip, oracle, tuning, planes):
     """DFX_STREAM_PLANES: all 64-channel input chunks resident in LDS (staged once per work
     item) vs one chunk at a time, on inputs with several chunks."""
+    tuning.setenv("DFX_STREAM_DIRECT", "0")   # conv_stream.cuh is the subject here (conv_direct.cuh: tests below)
     tuning.setenv("DFX_STREAM_PLANES", planes)
     cases = [c for c in STREAM_SHAPES if c.ic > 64] + [
         C.ConvCase("ic192", 3, 192, 9, 12, 160, 144, dst_dt=C.U8, wide=True),
@@ -236,16 +248,15 @@ def test_stream_variant_resident_input_chunks(hip, oracle, tuning, planes):
             hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), info.kernel_name.decode() + " " + case.ident())
 
 
-@pytest.mark.parametrize("mode", ["DFX_STREAM_OCC_PAR", "DFX_STREAM_SPLIT"])
-def test_stream_variant_chunk_parallel_and_split(hip, oracle, tuning, mode):
-    """(unit, output chunk) work items for unfused ops, and fused ops run as two such
-    launches through a u8 intermediate: forced on shapes that would not pick them."""
-    tuning.setenv(mode, "1")
+def test_stream_variant_chunk_parallel(hip, oracle, tuning):
+    """(unit, output chunk) work items for unfused ops, forced on shapes that would not pick them.  (The two-launch
+    execution of fused ops that round 2 tested here is gone: conv_direct.cuh serves those shapes in one launch.)"""
+    tuning.setenv("DFX_STREAM_DIRECT", "0")   # conv_stream.cuh is the subject here (conv_direct.cuh: tests below)
+    tuning.setenv("DFX_STREAM_OCC_PAR", "1")
     cases = STREAM_SHAPES + C.dtype_matrix(C.SMALL) + [C.CONFIG3_SMALL, replace(C.CONFIG3_SMALL, dst_dt=C.U8, wide=True)]
-    if mode == "DFX_STREAM_OCC_PAR":
-        cases = [C.unfused(c) if c.oc1x1 else c for c in cases] + [
-            C.ConvCase("oc512", 3, 64, 7, 7, 512, 0, dst_dt=C.S8, relu0=False),
-            C.ConvCase("oc320s2", 2, 48, 9, 11, 320, 0, stride=(2, 2), dst_dt=C.F32)]
+    cases = [C.unfused(c) if c.oc1x1 else c for c in cases] + [
+        C.ConvCase("oc512", 3, 64, 7, 7, 512, 0, dst_dt=C.S8, relu0=False),
+        C.ConvCase("oc320s2", 2, 48, 9, 11, 320, 0, stride=(2, 2), dst_dt=C.F32)]
     for grid in ("", "2"):
         if grid:
             tuning.setenv("DFX_STREAM_GRID", grid)
@@ -273,7 +284,6 @@ DIRECT_SHAPES = [
 def test_direct_weight_kernel(hip, oracle, tuning, grid):
     """fused ops with >= 64 channels on both sides run on conv_direct.cuh (weights straight from
     L2 into MFMA operands); also with DFX_NO_FAST (exact requant path) and many units per workgroup."""
-    tuning.setenv("DFX_STREAM_DIRECT", "1")   # (auto only picks it for deep first contractions)
     if grid:
         tuning.setenv("DFX_STREAM_GRID", grid)
     for nofast in ("0", "1"):
@@ -679,20 +689,20 @@ def test_concurrent_submits_on_several_streams(hip, oracle, tuning):
     own slot of the 16-entry queue ring (include/dfx.h), so the outputs must not mix.  20 streams x 3 launches =
     60 launches wrap the ring several times: a launch whose slot was last used on another stream waits for that
     launch on the device (slot events) instead of sharing its queue words.  Different inputs per stream; the
-    resident-weight kernel (device queue: many units per loader), a streamed one, and a split op submitted
-    first on the default stream and then on side streams."""
+    resident-weight kernel (device queue: many units per loader), a streamed one, and a direct-weight one
+    (eight waves) submitted first on the default stream and then on side streams."""
     import torch
     cases = [(C.ConvCase("conc_q", 6, 32, 120, 96, 64, 0, dst_dt=C.F32), 20, None),
              (replace(C.CONFIG3_SMALL, bs=5, dst_dt=C.U8), 20, None),
              (C.ConvCase("conc_s", 3, 128, 14, 14, 128, 256, dst_dt=C.S32), 4, None),
-             (C.ConvCase("conc_split", 2, 128, 7, 7, 256, 256, dst_dt=C.U8), 4, "DFX_STREAM_SPLIT")]
+             (C.ConvCase("conc_direct", 2, 128, 7, 7, 256, 512, dst_dt=C.U8), 4, "DFX_DIRECT_NW=8")]
     for case, nstreams, switch in cases:
         if switch:
-            tuning.setenv(switch, "1")
+            tuning.setenv(*switch.split("="))
         data = C.generate(case)
         op = hip.make_conv(case, data)
         if switch:
-            assert op.info().kernel_name.decode().startswith("split:"), op.info().kernel_name
+            assert op.info().kernel_name.decode().startswith("conv_direct_kernel<nw8"), op.info().kernel_name
         rng = np.random.default_rng(11)
         nsrc = min(nstreams, 5)   # distinct inputs (stream i uses input i % nsrc)
         srcs_np = [rng.integers(0, 256, data["src"].shape).astype(np.uint8) for _ in range(nsrc)]
@@ -715,7 +725,7 @@ def test_concurrent_submits_on_several_streams(hip, oracle, tuning):
                                      "stream %d launch %d %s" % (i, rep, case.name))
         op.close()
         if switch:
-            tuning.setenv(switch, None)
+            tuning.setenv(switch.split("=")[0], None)
 
 
 def test_concurrent_submits_from_two_host_threads(hip, oracle):
