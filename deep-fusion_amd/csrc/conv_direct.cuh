@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
   constexpr int NP1 = PXW1 / PX1;             // conv1 passes per group
   // conv1 weight ring depth in k-blocks (G fragments each).  Even, and it divides ocb (a multiple of WO): the
   // ring never has to stop at the end of a group.
-  constexpr int RD1 = (WO % 4 != 0 || PX1 * G > 4) ? 2 : 4;
+  constexpr int RD1 = (WO % 4 != 0 || PX1 * G > 4) ? 2 : 4;  // (4 with PX1 * G = 8: 256 VGPRs and spills, 3-6 % slower)
   static_assert(WO % RD1 == 0, "the conv1 ring must divide the number of output blocks");
   constexpr int NF = PXW < 2 ? PXW : 2;       // MFMAs issued before the k-block's LDS prefetch
   DFX_STAMP(t_entry);
@@ -235,6 +235,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
   bool prof_first = true;
 #endif
 
+  // (Tried and dropped in round 3: issuing a unit's tile loads one unit ahead, after the last K loop of the unit
+  // before it -- 3-6 % SLOWER at res3 / res4, profiles/r03/ab_direct_tile_ahead.txt: the loads return in order, so
+  // they cannot go out earlier than that without stalling the weight rings, and the 16-24 extra live registers
+  // cost more than the one store epilogue they overlap.)
   for (int unit = blockIdx.x; unit < g.total_units; unit += gridDim.x) {
     const UnitGeo ug = unit_geo(unit);
     // (keeps the staging table's decoded fields and addresses from being hoisted out of the unit loop: as loop
