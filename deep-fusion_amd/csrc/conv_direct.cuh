@@ -47,6 +47,9 @@ constexpr int DK_POS = 80;   // LDS bytes per halo-tile position and plane (64 +
 constexpr int DK_TQ = 6;     // tile granules a thread holds in registers at once (4 waves: 24 KB of tile, 8 waves: 48 KB)
 constexpr int DK_RD = 9;     // conv0 weight ring: k-blocks in flight per wave (multiple of 3)
 constexpr int DK_STAGE = 32 * 144;  // per wave: 1-byte store staging (aliases the dead tile)
+#ifndef DK_QM_TRANSPOSE
+#define DK_QM_TRANSPOSE 0           // 1: the conversion-free routes store through the LDS transpose too (A/B aid)
+#endif
 
 struct DirectGeom {
   int ni, thv, twv;     // unit = ni whole images (ni > 1 only if thv == oh && twv == ow) x thv x twv px
@@ -270,14 +273,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
     const bool even0 = nkb0 % DK_RD == 0;
     // ---- stage the whole halo tile (all planes) ----
     DK_T_ISSUE(ug.n0, ug.iy0, ug.ix0, ug.nimg);
+    // (slot -> image, row, column of the unit: f32-reciprocal quotients as in the staging table; the integer
+    // division sequences of the slot table and of conv0's PXW fragment bases were ~350 instructions per unit)
+    const float r_px = 1.0f / __int2float_rn(thc * twc), r_tw = 1.0f / __int2float_rn(twc);
     if (wave < NPB) {  // slot table: wave w fills pixel block w
       const int slot = 32 * wave + l31;
       const int pc = min(slot, npx - 1);
-      const int img = pc / (thc * twc), r = pc - img * (thc * twc);
-      const int ty = r / twc, tx = r - ty * twc;
+      int r, tx;
+      const int img = divmod(pc, thc * twc, r_px, r);
+      const int ty = divmod(r, twc, r_tw, tx);
+      // (pc is clamped to the unit's last pixel.  QM != 0: empty slots repeat that pixel's offset -- see the store
+      // epilogue; otherwise they are marked)
       if (h == 0)
-        pxoff[slot] = slot < npx ? (unsigned)(((ug.n0 + img) * a.oh + ug.y0 + ty) * a.ow + ug.x0 + tx) * row_bytes
-                                 : 0xffffffffu;
+        pxoff[slot] = (slot < npx || (QM != 0 && !DK_QM_TRANSPOSE)) ? (unsigned)(((ug.n0 + img) * a.oh + ug.y0 + ty) * a.ow + ug.x0 + tx) * row_bytes
+                                                                   : 0xffffffffu;
     }
     DK_T_COMMIT();
     for (int q = tid + DK_THREADS * DK_TQ; q < tile_q; q += DK_THREADS) {  // the part beyond the register prefetch
@@ -307,8 +316,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
     for (int p = 0; p < PXW; ++p) {
       const int slot = 32 * (wp * PXW + p) + l31;
       const int pc = min(slot, npx - 1);
-      const int img = pc / (thc * twc), r = pc - img * (thc * twc);
-      const int ty = r / twc, tx = r - ty * twc;
+      int r, tx;
+      const int img = divmod(pc, thc * twc, r_px, r);
+      const int ty = divmod(r, twc, r_tw, tx);
       fbyte[p] = (img * lhw + ty * a.sh * g.lw + tx * a.sw) * DK_POS + 16 * h;
       mid_w[p] = mid + slot * g.mid_stride + h * 16;
     }
@@ -545,7 +555,31 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
               sc[cc] = scale1[chb + cc];
               zf[cc] = 0.0f;
             }
-            if constexpr (ESZ == 1 && G == 4) {
+            if constexpr (MODE >= 2 && !DK_QM_TRANSPOSE) {
+              // conversion-free routes: straight from the accumulators, one dword (this lane's 4 channels) per pixel;
+              // a wave instruction writes two pixels' 128 contiguous bytes.  No LDS round trip, no predicate: the slot
+              // table points the slots behind the unit's last pixel AT that pixel, and those slots hold exactly its
+              // values (they read its input positions in conv0), so their stores repeat its bytes.
+              if (chb < a.oc1) {
+#pragma unroll
+                for (int p = 0; p < PX1; ++p) {
+                  v4i o4[4];
+#pragma unroll
+                  for (int eq = 0; eq < 4; ++eq) o4[eq] = *reinterpret_cast<const v4i *>(pxoff + 32 * (pb0 + p) + 8 * eq + 4 * h);
+#pragma unroll
+                  for (int e = 0; e < 16; ++e) {
+                    unsigned pk = 0;
+#pragma unroll
+                    for (int cc = 0; cc < G; ++cc) {
+                      const float x = __int_as_float(acc1[p][cc][e]);
+                      pk = __builtin_amdgcn_cvt_pk_u8_f32(MODE == 3 ? __builtin_fmaf(x, sc[cc], bs[cc]) : __fmul_rn(__fadd_rn(x, bs[cc]), sc[cc]), cc, pk);
+                    }
+                    const unsigned off = (unsigned)o4[e >> 2][e & 3] + chbE;
+                    DFX_STORE(reinterpret_cast<unsigned *>(dst_b + DK_CHK(11, (long long)off, 4, g.dst_bytes)), pk);
+                  }
+                }
+              }
+            } else if constexpr (ESZ == 1 && G == 4) {
               // 1-byte outputs: transpose 32 px x 128 B through LDS, 16-byte stores (see conv_stream.cuh)
               unsigned char *stg = tile0 + wave * DK_STAGE;
 #pragma unroll
