@@ -57,7 +57,14 @@ struct DirectGeom {
   int lh, lw, npos;     // halo tile rows / cols per image; positions = ni * lh * lw
   int icb;              // 32-channel input blocks
   int n_planes;         // 64-channel planes of the tile = (icb + 1) / 2
-  int plane_bytes;      // npos * DK_POS
+  int plane_bytes;      // ni * img_pitch
+  // byte pitches of the tile: position (img, ly, lx) of a plane sits at img * img_pitch + ly * row_pitch + lx *
+  // DK_POS.  row_pitch = lw * DK_POS + 16 c, img_pitch = lh * row_pitch + 16 c': the host picks c, c' (0..15) so
+  // that the 16 lanes of every ds_read_b128 lane group of a pixel fragment fall into 16 different 16-byte bank
+  // columns.  (With the plain pitches consecutive slots of one output row are conflict-free -- DK_POS is 5 x 16 --
+  // but a 32-slot block wraps over 2-5 output rows and the row gap broke the pattern: 47 % of the LDS cycles at
+  // res4 were bank conflicts, profiles/r03/final pmc.)
+  int row_pitch, img_pitch;
   int ocb;              // conv0 output blocks, padded to a multiple of WO
   int n_g1;             // conv1 groups of G column blocks
   int mid_stride;       // 32 * ocb + 16
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
   }
   // ---- tile staging: granule q = tid + 256 i -> plane q / (4 npos), position, 16-byte chunk q & 3 ----
   const int lhw = g.lh * g.lw;
-  const int row_skip = (g.lw - a.kw) * DK_POS;  // bytes from the last tap of a kernel row to the next row's first
+  const int row_skip = g.row_pitch - a.kw * DK_POS;  // bytes from the last tap of a kernel row to the next row's first
   const int tile_q1 = g.npos * 4, tile_q = tile_q1 * g.n_planes;
   int tq_pos[DK_TQ];  // plane << 28 | img << 20 | ly << 10 | lx
   // (quotients through f32 reciprocals with a +-1 fix-up: every dividend is < 2^22; the integer division sequence
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
       const int q_ = tid + DK_THREADS * i;                                              \
       const int pl_ = (tq_pos[i] >> 28) & 15, img_ = (tq_pos[i] >> 20) & 255;           \
       const int ly_ = (tq_pos[i] >> 10) & 1023, lx_ = tq_pos[i] & 1023;                 \
-      const int lo_ = q_ < tile_q ? pl_ * g.plane_bytes + (img_ * lhw + ly_ * g.lw + lx_) * DK_POS + 16 * (q_ & 3) \
+      const int lo_ = q_ < tile_q ? pl_ * g.plane_bytes + img_ * g.img_pitch + ly_ * g.row_pitch + lx_ * DK_POS + 16 * (q_ & 3) \
                                   : g.n_planes * g.plane_bytes; /* dump slot */          \
       *reinterpret_cast<v4i *>(tile0 + lo_) = ((tv_ok >> i) & 1) ? tv[i] ^ x80 : x80;   \
     }                                                                                   \
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
       const int n_ = min(ug.n0 + img, a.bs - 1), y_ = min(max(iy, 0), a.ih - 1), x_ = min(max(ix, 0), a.iw - 1);
       const long long o = (((long long)n_ * a.ih + y_) * a.iw + x_) * a.ic + min(64 * pl + 16 * j, a.ic - 16);
       const v4i v = *reinterpret_cast<const v4i *>(a.src + DK_CHK(2, o, 16, g.src_bytes));
-      *reinterpret_cast<v4i *>(tile0 + pl * g.plane_bytes + pos * DK_POS + 16 * j) = ok ? v ^ x80 : x80;
+      *reinterpret_cast<v4i *>(tile0 + pl * g.plane_bytes + img * g.img_pitch + ly * g.row_pitch + lx * DK_POS + 16 * j) = ok ? v ^ x80 : x80;
     }
     if (first_unit) {  // the constants' LDS-DMA (see above)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
       int r, tx;
       const int img = divmod(pc, thc * twc, r_px, r);
       const int ty = divmod(r, twc, r_tw, tx);
-      fbyte[p] = (img * lhw + ty * a.sh * g.lw + tx * a.sw) * DK_POS + 16 * h;
+      fbyte[p] = img * g.img_pitch + ty * a.sh * g.row_pitch + tx * a.sw * DK_POS + 16 * h;
       mid_w[p] = mid + slot * g.mid_stride + h * 16;
     }
     // requant 0 -> u8 -> mid, in the 1x1 stage's k order: byte 16h + 4q + i of block ob = channel 32 ob + 8q + 4h + i.

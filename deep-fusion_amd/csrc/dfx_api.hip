@@ -484,7 +484,8 @@ static bool pick_direct_geometry(const dfx_conv_desc &d, int NW, int WO, int G, 
     const int lh = (thv - 1) * d.sh + d.kh, lw = (twv - 1) * d.sw + d.kw;
     if (lh >= 1024 || lw >= 1024 || ni >= 256) return;
     const long long npos = (long long)ni * lh * lw;
-    const size_t tile = std::max((size_t)((long long)g.n_planes * npos * DK_POS + 16), stage_bytes);
+    // (+ 240 bytes per row and per image: the bank-spreading pads of the pitches, chosen below)
+    const size_t tile = std::max((size_t)((long long)g.n_planes * ni * ((long long)lh * (lw * DK_POS + 240) + 240) + 16), stage_bytes);
     if (fixed + tile > lds_max) return;
     const double groups = (double)((d.bs + ni - 1) / ni);
     const double units = groups * ((d.oh + thv - 1) / thv) * ((d.ow + twv - 1) / twv);
@@ -506,7 +507,42 @@ static bool pick_direct_geometry(const dfx_conv_desc &d, int NW, int WO, int G, 
   g.uy = (d.oh + g.thv - 1) / g.thv;
   g.ux = (d.ow + g.twv - 1) / g.twv;
   g.total_units = (d.bs + g.ni - 1) / g.ni * g.uy * g.ux;
-  g.plane_bytes = g.npos * DK_POS;
+  // Pitches: 16 c / 16 c' bytes of padding per tile row / image so that the 16 lanes of each ds_read_b128 lane
+  // group ({0-3,12-15,20-27}, {4-11,16-19,28-31} of either half wave) read 16 different 16-byte bank columns --
+  // brute force over c, c', cost = extra LDS cycles summed over the unit's pixel blocks (0 = conflict-free).
+  {
+    const int px_img = g.thv * g.twv, npx = g.ni * px_img;
+    static const int grp[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                   {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+    long long best_cost = -1;
+    int best_c = 0, best_ci = 0;
+    for (int ci = 0; ci < (g.ni > 1 ? 16 : 1); ++ci)
+      for (int c = 0; c < 16; ++c) {
+        const long long rp = (long long)g.lw * DK_POS + 16 * c, ip = (long long)g.lh * rp + 16 * ci;
+        long long cost = 0;
+        for (int b = 0; b < npb; ++b)
+          for (int gi = 0; gi < 2; ++gi) {
+            int cnt[16] = {0};
+            long long seen[16][16];
+            for (int k = 0; k < 16; ++k) {
+              const int pc = std::min(32 * b + grp[gi][k], npx - 1);
+              const int img = pc / px_img, r = pc % px_img, ty = r / g.twv, tx = r % g.twv;
+              const long long addr = img * ip + (long long)ty * d.sh * rp + (long long)tx * d.sw * DK_POS;
+              const int col = (int)((addr / 16) % 16);
+              bool dup = false;  // identical addresses broadcast
+              for (int j = 0; j < cnt[col]; ++j) dup = dup || seen[col][j] == addr;
+              if (!dup) seen[col][cnt[col]++] = addr;
+            }
+            int worst = 1;
+            for (int k = 0; k < 16; ++k) worst = std::max(worst, cnt[k]);
+            cost += worst - 1;
+          }
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_c = c; best_ci = ci; }
+      }
+    g.row_pitch = g.lw * DK_POS + 16 * best_c;
+    g.img_pitch = g.lh * g.row_pitch + 16 * best_ci;
+  }
+  g.plane_bytes = g.ni * g.img_pitch;
   g.off_pxoff = (int)round16(std::max((size_t)g.n_planes * (size_t)g.plane_bytes + 16, stage_bytes));
   g.off_mid = g.off_pxoff + 4 * M;
   g.off_cst = g.off_mid + M * g.mid_stride;
@@ -965,7 +1001,11 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     h->block = 256;
     launch_conv_generic(a, nullptr, &h->grid, &h->lds);
     a.rows_per_unit = 0;
-    snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_generic_kernel<dt=%d>", d.dst_dt);
+    // The streamed- and direct-weight MFMA kernels hold dst offsets in 32 bits: an op whose dst reaches 4 GiB
+    // runs on the scalar kernel, and its name says why (dfx_conv_query).
+    const bool big_dst = (long long)d.bs * d.oh * d.ow * (d.oc1x1 ? d.oc1x1 : d.oc) * (long long)dt_size(d.dst_dt) >= (1LL << 32) - 16;
+    snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_generic_kernel<dt=%d>%s", d.dst_dt,
+             big_dst && d.force_variant != DFX_VARIANT_GENERIC ? " [dst >= 4 GiB: no MFMA kernel (32-bit dst offsets)]" : "");
   }
   *out = h;
   return DFX_OK;

@@ -328,6 +328,23 @@ def test_direct_weight_kernel_unit_sizes(hip, oracle, tuning, split, switch):
         hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), name + " " + case.ident())
 
 
+def test_dst_of_4_gib_is_named_in_kernel_name(hip):
+    """the streamed- / direct-weight MFMA kernels keep dst offsets in 32 bits: an op whose dst reaches 4 GiB is
+    created on the scalar kernel and dfx_conv_query says so (create only: nothing of that size is allocated)"""
+    # 66 x 128 x 128 px x 1024 channels x 4 B = 4.1 GiB
+    op = hip.dfa.Conv((66, 128, 128, 128), (128, 128, 3, 3), dst_dt=C.F32, oc1x1=1024)
+    try:
+        name = op.info().kernel_name.decode()
+        assert name.startswith("conv_generic_kernel") and "dst >= 4 GiB" in name, name
+    finally:
+        op.close()
+    op = hip.dfa.Conv((8, 128, 128, 128), (128, 128, 3, 3), dst_dt=C.F32, oc1x1=1024)   # the same layer under the limit
+    try:
+        assert op.info().kernel_name.decode().startswith("conv_direct_kernel"), op.info().kernel_name
+    finally:
+        op.close()
+
+
 def _random_cases(n, seed, big=False):
     """seeded random shapes inside what the reference's init_conf admits: channels multiples
     of 16, any kernel / stride / padding with a non-empty output"""
