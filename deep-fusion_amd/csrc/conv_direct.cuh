@@ -6,36 +6,54 @@
 // multi-chunk accumulation of :193-216, any kernel size / stride / padding, channels
 // multiples of 16), different decomposition.  conv_stream.cuh gives every wave 32 pixels and
 // ALL output channels, so the four waves share each weight fragment through LDS: a staging
-// copy and a workgroup barrier per 8 MFMAs.  Here a workgroup still owns a unit of up to 128
-// output pixels, but
-//  * in conv0 wave w owns output-channel blocks w, w+WO, ... for PXW = WO of the unit's four
-//    32-pixel blocks (WO x WP waves, WO * WP = 4).  Its weight fragments are private: they are
-//    fetched with one coalesced 1 KB global load per 32-deep k-block into a register ring
-//    DK_RD k-blocks deep (the L2 latency is ~1k cycles, a k-block is PXW MFMAs), and feed the
-//    MFMA directly as the A operand.  No weight staging, no barrier inside the K loop.
-//  * the input halo tile is staged ONCE per unit with all its 64-channel planes
-//    ([plane][position][80 B]: the odd multiple of 16 spreads consecutive positions over the
-//    banks, so a fragment address is base + a wave-uniform offset), read-only afterwards;
+// copy and a workgroup barrier per 8 MFMAs.  Here a workgroup of NW = 4 or 8 waves owns a unit
+// of NPB = 1, 2 or 4 blocks of 32 output pixels, and
+//  * in conv0 the waves split the output-channel blocks WO ways and the pixel blocks WP = NW / WO ways: wave
+//    (wo, wp) owns blocks wo, wo + WO, ... for its PXW = NPB / WP pixel blocks.  Its weight fragments are
+//    private: ONE stream of 1 KB blocks (k-blocks 0 .. nkb0 - 1 of each of its output blocks) through a ring of
+//    DK_RD register quadruples, buffer_load_dwordx4 with a scalar offset, fed to the MFMA as the A operand.
+//    No weight staging, no barrier inside the K loop.
+//  * the input halo tile is staged ONCE per unit with all its 64-channel planes ([plane][image][row][col][80 B];
+//    80 = 5 x 16 spreads consecutive columns over the bank columns, and the host pads the row / image pitch by
+//    16 c bytes so that a 32-pixel block that wraps over several output rows still reads without bank conflicts:
+//    DirectGeom::row_pitch), read-only afterwards; a fragment address is base + a wave-uniform offset;
 //  * the u8 intermediate goes to LDS (mid[slot][oc], the reference keeps it in xmm registers,
-//    jit_conv_kernel.cc:275-277); one barrier; then conv1 with the same idea: wave w owns
-//    1x1 output groups w, w+WO1, ... (G column blocks each, the channel permutation and
-//    store path of conv_mfma.cuh), A fragments from mid, B fragments from global.
-// Three workgroup barriers per unit in all.  Requantisation, fast/exact paths, the LDS
-// transpose for 1-byte outputs and the unit geometry are those of conv_stream.cuh.
+//    jit_conv_kernel.cc:275-277); one barrier; then conv1 with the same idea: WO1 x WP1 waves, wave (wo1, wp1)
+//    owns 1x1 output groups wo1, wo1 + WO1, ... (G column blocks each, the channel permutation of
+//    conv_mfma.cuh) for its PXW1 pixel blocks, PX1 of them per pass; A fragments from mid, B fragments through
+//    a second ring that is primed before the barrier and runs on across passes, groups and store epilogues.
+// Three workgroup barriers per unit.
 //
-// Round 3:
-//  * A unit has NPB = 1, 2 or 4 blocks of 32 pixel slots (it used to be 4 always: a 14x14 or 7x7 layer
-//    then yields 196 / 64 units for 512 workgroup slots, one wave per SIMD on the CUs that get any).
-//    The four waves split output blocks WO ways and pixel blocks WP = 4 / WO ways in conv0 (PXW =
-//    NPB / WP pixel blocks per wave), WO1 x WP1 in conv1: with one pixel block per unit every wave
-//    streams its own quarter of BOTH weight sets (before, every wave streamed the whole 1x1 set).
-//    The host picks the largest NPB that still fills three quarters of the workgroup slots.
+// What round 3 changed, each with its measurement (N = 128, u8 out; profiles/r03/):
+//  * The K loops are BRANCH-FREE around their loads.  hipcc's wait-count pass merges the states of the two sides
+//    of a branch, so with the ring refill inside `if (kb < nkb0)` it counted the ring down to vmcnt(0) once per
+//    DK_RD k-blocks: the "9-deep" ring was drained every round (85 cycles per MFMA at res4; direct_sweep_1 /
+//    stamps_direct_1 before, _3 / _4 after).  Whole rounds now run unconditionally (EVEN: nkb0 a multiple of
+//    DK_RD, every 3x3 layer -- refills run on into the next output block and the requant of one block hides
+//    under the loads of the next; otherwise the last k-blocks of a block run unpipelined).  conv1's ring depth
+//    divides the (padded) block count, so that loop has no odd tail at all.
+//  * Weights come through buffer loads (scalar offset + one lane-offset VGPR).  With flat addresses hipcc hoisted a
+//    64-bit per-lane pointer per ring slot out of the unit loop and spilled 70-84 VGPRs (~20 k cycles of scratch
+//    reloads per unit).  Both stages' constants live in LDS (LDS-DMA at kernel entry): a global load in the store
+//    epilogue waited for the ring.
+//  * NW = 8 (one workgroup per CU, two waves per SIMD) for layers whose units do not fill the CUs twice: res4
+//    39 -> 35 us, res5 58 -> 45 us (and one launch instead of round 2's two: 79 us).
+//  * The requant routes are template parameters for u8 output (QM: generic / fma + magic / fma + fma).  As
+//    run-time branches around the store epilogue they made hipcc copy every accumulator out of its MFMA tuple
+//    (64 v_mov per 32 x 128 block, 256 VGPRs, spills).  The specialised kernels fit PX1 = 2 pixel blocks per conv1
+//    pass (W1 crosses the L2 port half as often) and store dwords straight from the accumulators.
 //  * Requant without int -> float conversions where the host proves the ranges (dfx_api.hip, as for
-//    conv_mfma_roles.cuh): stage 0 "fma" (g.m0: accumulators start from bits(2^23) + comp + bias, one
-//    v_fma_f32 + v_cvt_pk_u8_f32 per value), stage 1 "magic" (g.m1 = 2: start 1/(2 pi), v_add_f32 +
-//    v_mul_f32 + cvt; g.m1 = 3: one v_fma_f32 where the addend is exact) for u8 output -- 2 to 3 vector
-//    instructions per value instead of 5 (the requant + store stage was the longest of a unit: 14.8 k of
-//    52 k cycles at res4, profiles/stamps_direct.py).
+//    conv_mfma_roles.cuh): stage 0 "fma" (accumulators start from bits(2^23) + comp + bias, one v_fma_f32 +
+//    v_cvt_pk_u8_f32 per value), stage 1 "magic" (start 1/(2 pi), v_add_f32 + v_mul_f32 + cvt) or "fma".
+//  * Bank-conflict-free tile pitches (above): 47 % of the LDS cycles at res4 were conflicts; res4 30.2 -> 28.2 us.
+//  * Set-up arithmetic: f32-reciprocal quotients instead of integer division sequences in the staging table and
+//    the per-unit slot decode (~350 instructions per unit).
+// Tried and dropped (A/B logs in profiles/r03/ab_direct_*.txt): priming the conv0 ring before the tile is staged,
+// conv1 ring depth 4 with PX1 = 2, tile loads one unit ahead.
+// Where the time goes now (stamps build, profiles/r03/stamps_direct_*.txt): res4 conv0 K loop 45 % (the matrix
+// pipe is 75 % busy inside it), conv1 20 %, tile staging 10 %, store epilogue 9 %, ~5.5 k cycles (9 %) from kernel
+// entry to the first unit.  The weight stream is the floor of res5: 3.4 MB per 32-pixel unit through one CU's L2
+// port at ~44 B/clk.
 #pragma once
 
 #include "conv_mfma.cuh"
