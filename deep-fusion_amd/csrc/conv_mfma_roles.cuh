@@ -414,7 +414,9 @@ __global__ __launch_bounds__(RL_THREADS, (RL_WAVES + 3) / 4) void conv_mfma_role
           __builtin_amdgcn_global_load_lds((global_void *)(s + q), (lds_void *)(d + 64 * j), 16, 0, 0);
       }
       // The first TWO units of stream `steam` (both static: coop0 / coop1): all their global loads are issued
-      // before the first LDS write.  (Until round 3 the loader staged its second unit itself before the barrier:
+      // before the first LDS write.  (Tried late in round 3: waiting only for W0 + the first units at the barrier and
+      // writing the second units behind it -- the barrier moved from 8.6 k to 7.4 k cycles after entry in the
+      // stamps build, the launch time did not move: 28.8-29.6 us both ways, profiles/r03/ab_roles_defer_second_units.txt.)  (Until round 3 the loader staged its second unit itself before the barrier:
       // its table set-up put those loads ~3 k cycles behind everybody else's and the whole workgroup waited at the
       // barrier for them -- stamps: compute waves there after 4.6-5.9 k cycles, loaders after 6.9 k.)
       constexpr int NTL = 4;  // 16-byte chunks per thread and unit held in registers at once
