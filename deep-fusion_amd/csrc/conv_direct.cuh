@@ -49,7 +49,11 @@
 //  * Set-up arithmetic: f32-reciprocal quotients instead of integer division sequences in the staging table and
 //    the per-unit slot decode (~350 instructions per unit).
 // Tried and dropped (A/B logs in profiles/r03/ab_direct_*.txt): priming the conv0 ring before the tile is staged,
-// conv1 ring depth 4 with PX1 = 2, tile loads one unit ahead.
+// conv1 ring depth 4 with PX1 = 2, tile loads one unit ahead, and RASTER units (128 consecutive pixels of the batch
+// across row and image ends, so that every unit is full: 784 instead of 896 units at 28 x 28) -- bit-exact on all
+// shapes, but the taller tile (10 rows instead of 6), its LDS and the per-unit segment table's scalars cost more
+// than the full units won: res3 44.9 vs 38.5 us on one box, and the extra live scalars slowed the rectangular
+// path by 8-15 % as well (this kernel sits at the SGPR limit: ~100 spilled to VGPR lanes).
 // Where the time goes now (stamps build, profiles/r03/stamps_direct_*.txt): res4 conv0 K loop 45 % (the matrix
 // pipe is 75 % busy inside it), conv1 20 %, tile staging 10 %, store epilogue 9 %, ~5.5 k cycles (9 %) from kernel
 // entry to the first unit.  The weight stream is the floor of res5: 3.4 MB per 32-pixel unit through one CU's L2
@@ -196,25 +200,28 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
     return q;
   };
   const float r_tq1 = 1.0f / __int2float_rn(tile_q1), r_lhw = 1.0f / __int2float_rn(lhw), r_lw = 1.0f / __int2float_rn(g.lw);
+  auto tq_fill = [&](int (&tqp)[DK_TQ], int qbase) {
 #pragma unroll
-  for (int i = 0; i < DK_TQ; ++i) {
-    const int q = min(tid + DK_THREADS * i, tile_q - 1);
-    int ql, r, lx;
-    const int pl = divmod(q, tile_q1, r_tq1, ql);
-    const int img = divmod(ql >> 2, lhw, r_lhw, r);
-    const int ly = divmod(r, g.lw, r_lw, lx);
-    tq_pos[i] = (pl << 28) | (img << 20) | (ly << 10) | lx;
-  }
+    for (int i = 0; i < DK_TQ; ++i) {
+      const int q = min(qbase + tid + DK_THREADS * i, tile_q - 1);
+      int ql, r, lx;
+      const int pl = divmod(q, tile_q1, r_tq1, ql);
+      const int img = divmod(ql >> 2, lhw, r_lhw, r);
+      const int ly = divmod(r, g.lw, r_lw, lx);
+      tqp[i] = (pl << 28) | (img << 20) | (ly << 10) | lx;
+    }
+  };
+  tq_fill(tq_pos, 0);
   const v4i x80 = v4i{(int)0x80808080, (int)0x80808080, (int)0x80808080, (int)0x80808080};
   v4i tv[DK_TQ];
   int tv_ok = 0;
   // (branch-free loads: hipcc waits vmcnt(0) inside a branch around a load)
-#define DK_T_ISSUE(N0, IY0, IX0, NIMG)                                                  \
+#define DK_T_ISSUE(TQP, QB, N0, IY0, IX0, NIMG)                                         \
   do {                                                                                  \
     _Pragma("unroll") for (int i = 0; i < DK_TQ; ++i) {                                 \
-      const int q_ = tid + DK_THREADS * i;                                              \
-      const int pl_ = (tq_pos[i] >> 28) & 15, img_ = (tq_pos[i] >> 20) & 255;           \
-      const int ly_ = (tq_pos[i] >> 10) & 1023, lx_ = tq_pos[i] & 1023;                 \
+      const int q_ = (QB) + tid + DK_THREADS * i;                                       \
+      const int pl_ = (TQP[i] >> 28) & 15, img_ = (TQP[i] >> 20) & 255;                 \
+      const int ly_ = (TQP[i] >> 10) & 1023, lx_ = TQP[i] & 1023;                       \
       const int iy_ = (IY0) + ly_, ix_ = (IX0) + lx_, cb_ = 64 * pl_ + 16 * (q_ & 3);   \
       const bool ok_ = q_ < tile_q && img_ < (NIMG) && iy_ >= 0 && iy_ < a.ih && ix_ >= 0 && \
                        ix_ < a.iw && cb_ < a.ic;                                        \
@@ -226,12 +233,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
       tv_ok = ok_ ? (tv_ok | (1 << i)) : (tv_ok & ~(1 << i));                           \
     }                                                                                   \
   } while (0)
-#define DK_T_COMMIT()                                                                   \
+#define DK_T_COMMIT(TQP, QB)                                                            \
   do {                                                                                  \
     _Pragma("unroll") for (int i = 0; i < DK_TQ; ++i) {                                 \
-      const int q_ = tid + DK_THREADS * i;                                              \
-      const int pl_ = (tq_pos[i] >> 28) & 15, img_ = (tq_pos[i] >> 20) & 255;           \
-      const int ly_ = (tq_pos[i] >> 10) & 1023, lx_ = tq_pos[i] & 1023;                 \
+      const int q_ = (QB) + tid + DK_THREADS * i;                                       \
+      const int pl_ = (TQP[i] >> 28) & 15, img_ = (TQP[i] >> 20) & 255;                 \
+      const int ly_ = (TQP[i] >> 10) & 1023, lx_ = TQP[i] & 1023;                       \
       const int lo_ = q_ < tile_q ? pl_ * g.plane_bytes + img_ * g.img_pitch + ly_ * g.row_pitch + lx_ * DK_POS + 16 * (q_ & 3) \
                                   : g.n_planes * g.plane_bytes; /* dump slot */          \
       *reinterpret_cast<v4i *>(tile0 + lo_) = ((tv_ok >> i) & 1) ? tv[i] ^ x80 : x80;   \
@@ -297,7 +304,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
     v4i wr[DK_RD];
     const bool even0 = nkb0 % DK_RD == 0;
     // ---- stage the whole halo tile (all planes) ----
-    DK_T_ISSUE(ug.n0, ug.iy0, ug.ix0, ug.nimg);
+    DK_T_ISSUE(tq_pos, 0, ug.n0, ug.iy0, ug.ix0, ug.nimg);
     // (slot -> image, row, column of the unit: f32-reciprocal quotients as in the staging table; the integer
     // division sequences of the slot table and of conv0's PXW fragment bases were ~350 instructions per unit)
     const float r_px = 1.0f / __int2float_rn(thc * twc), r_tw = 1.0f / __int2float_rn(twc);
@@ -313,18 +320,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
         pxoff[slot] = (slot < npx || (QM != 0 && !DK_QM_TRANSPOSE)) ? (unsigned)(((ug.n0 + img) * a.oh + ug.y0 + ty) * a.ow + ug.x0 + tx) * row_bytes
                                                                    : 0xffffffffu;
     }
-    DK_T_COMMIT();
-    for (int q = tid + DK_THREADS * DK_TQ; q < tile_q; q += DK_THREADS) {  // the part beyond the register prefetch
-      const int pl = q / tile_q1, ql = q - pl * tile_q1;
-      const int pos = ql >> 2, j = ql & 3;
-      const int img = pos / lhw, r = pos - img * lhw;
-      const int ly = r / g.lw, lx = r - ly * g.lw;
-      const int iy = ug.iy0 + ly, ix = ug.ix0 + lx;
-      const bool ok = img < ug.nimg && iy >= 0 && iy < a.ih && ix >= 0 && ix < a.iw && 64 * pl + 16 * j < a.ic;
-      const int n_ = min(ug.n0 + img, a.bs - 1), y_ = min(max(iy, 0), a.ih - 1), x_ = min(max(ix, 0), a.iw - 1);
-      const long long o = (((long long)n_ * a.ih + y_) * a.iw + x_) * a.ic + min(64 * pl + 16 * j, a.ic - 16);
-      const v4i v = *reinterpret_cast<const v4i *>(a.src + DK_CHK(2, o, 16, g.src_bytes));
-      *reinterpret_cast<v4i *>(tile0 + pl * g.plane_bytes + img * g.img_pitch + ly * g.row_pitch + lx * DK_POS + 16 * j) = ok ? v ^ x80 : x80;
+    DK_T_COMMIT(tq_pos, 0);
+    // the part of the tile beyond the first DK_TQ granules per thread (stride-2 tiles, many planes): further batches
+    // of DK_TQ loads each, positions computed on the fly.  (Until late round 3 this was a loop of single dependent
+    // load -> store pairs with three integer divisions each: 744 of stride-2 res3's 2280 granules went through it.)
+    for (int qb = DK_THREADS * DK_TQ; qb < tile_q; qb += DK_THREADS * DK_TQ) {
+      int tq2[DK_TQ];
+      tq_fill(tq2, qb);
+      DK_T_ISSUE(tq2, qb, ug.n0, ug.iy0, ug.ix0, ug.nimg);
+      DK_T_COMMIT(tq2, qb);
     }
     if (first_unit) {  // the constants' LDS-DMA (see above)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
