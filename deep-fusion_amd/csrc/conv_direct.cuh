@@ -392,8 +392,18 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
     // the ring was drained every 9 k-blocks, 85 cycles per MFMA at res4).  EVEN (nkb0 a multiple of DK_RD, every
     // 3x3 layer): refills run on into the next output block, the requant of one block hides under the loads of
     // the next.  Otherwise whole rounds are branch-free and the last k-blocks of a block run unpipelined.
-    auto conv0_stage = [&](auto even_tag) {
-      constexpr bool EVEN = decltype(even_tag)::value;
+    // T9 (3x3 kernels, DK_RD = 9: one round = the nine taps of one 32-channel input block): the round's loop is
+    // free of scalar bookkeeping.  The generic loop tracks (tap, kernel column, input block) and the ring's
+    // (output block, k-block) with ~30 scalar instructions per k-block; a SIMD issues about one scalar instruction
+    // per 4 cycles over its waves, so two waves spent ~260 cycles of scalar issue per 256 (npb4) or 64 (npb1!)
+    // cycles of MFMA.  Here the tap of step i is i: the three kernel rows keep their own fragment addresses
+    // (arow[row][pixel block], advanced to the next input block right after the row's last prefetch of the round),
+    // the kernel column is the immediate offset of the ds_read, and the ring refills are rbase + i KB.
+    auto conv0_stage = [&](auto even_tag, auto t9_tag) {
+      constexpr bool EVEN = decltype(even_tag)::value, T9 = decltype(t9_tag)::value;
+      static_assert(!T9 || (EVEN && DK_RD == 9), "the 3x3 fast path walks whole rounds of nine taps");
+      int arow[3][PXW];
+      int icb_r = 0, f_ob = wo, f_kb0 = 0;  // the round's input block; the next REFILL round's output block / first k-block
       int l_tap = 0, l_tkw = 0, l_toff = 0, l_icb = 0;  // position of the NEXT k-block whose pixel fragments get loaded (runs two ahead)
       v4i fb[3][PXW];
 #define DK_LOAD_FB(SET)                                                                 \
@@ -408,8 +418,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
       if (EVEN) {
 #pragma unroll
         for (int i = 0; i < DK_RD; ++i) wr[i] = wload(r_next());
-        DK_LOAD_FB(0);
-        DK_LOAD_FB(1);
+        if constexpr (T9) {
+          f_ob = r_ob; f_kb0 = r_kb;
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int p = 0; p < PXW; ++p) arow[r][p] = fbyte[p] + r * g.row_pitch;
+#pragma unroll
+          for (int p = 0; p < PXW; ++p) {
+            fb[0][p] = *reinterpret_cast<const v4i *>(tile0 + arow[0][p]);
+            fb[1][p] = *reinterpret_cast<const v4i *>(tile0 + arow[0][p] + DK_POS);
+          }
+        } else {
+          DK_LOAD_FB(0);
+          DK_LOAD_FB(1);
+        }
       }
       for (int ob = wo; ob < g.ocb; ob += WO) {
         DFX_STAMP(t1b);
@@ -437,7 +460,39 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
         }
         DKF();
         int kb0 = 0;
-        for (; kb0 + DK_RD <= nkb0; kb0 += DK_RD) {
+        if constexpr (T9) {
+          for (; kb0 < nkb0; kb0 += DK_RD) {
+            const int nxt = icb_r + 1 == g.icb ? 0 : icb_r + 1;
+            const int dnext = ((nxt >> 1) - (icb_r >> 1)) * g.plane_bytes + ((nxt & 1) - (icb_r & 1)) * 32;
+            const int rbase = (min(f_ob, ob_last) * nkb0 + f_kb0) << 10;
+#pragma unroll
+            for (int i = 0; i < DK_RD; ++i) {
+#pragma unroll
+              for (int p = 0; p < NF; ++p) acc[p] = mfma_i8(wr[i], fb[i % 3][p], acc[p]);  // D0[oc][px]
+              DKF();
+              {
+                const int t = (i + 2) % 9, rr = t / 3, dx = t % 3;  // the tap two steps ahead (7, 8: the next round's 0, 1); constants once unrolled
+#pragma unroll
+                for (int p = 0; p < PXW; ++p)
+                  fb[(i + 2) % 3][p] = *reinterpret_cast<const v4i *>(tile0 + arow[rr][p] + dx * DK_POS);
+              }
+              DKF();
+#pragma unroll
+              for (int p = NF; p < PXW; ++p) acc[p] = mfma_i8(wr[i], fb[i % 3][p], acc[p]);
+              DKF();
+              wr[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(w0rs, (int)lane16, rbase + i * 1024, 0));
+              if (i == 0 || i == 3 || i == 6) {  // row i / 3 has issued its last prefetch of this round
+#pragma unroll
+                for (int p = 0; p < PXW; ++p) arow[i / 3][p] += dnext;
+              }
+              DKF();
+            }
+            icb_r = nxt;
+            f_kb0 += DK_RD;
+            if (f_kb0 == nkb0) { f_kb0 = 0; f_ob += WO; }
+          }
+        }
+        for (; !T9 && kb0 + DK_RD <= nkb0; kb0 += DK_RD) {
 #pragma unroll
           for (int i = 0; i < DK_RD; ++i) {
 #pragma unroll
@@ -476,7 +531,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
       }
 #undef DK_LOAD_FB
     };
-    if (even0) conv0_stage(TT{}); else conv0_stage(FF{});
+    if (even0 && a.kh == 3 && a.kw == 3 && DK_RD == 9) conv0_stage(TT{}, TT{});
+    else if (even0) conv0_stage(TT{}, FF{});
+    else conv0_stage(FF{}, FF{});
 
     // ---- conv1: this wave's groups x its PXW1 pixel blocks, PX1 at a time ----
     // Same scheme: the W1 fragments of this wave are one stream of blocks of G fragments (groups wo1, wo1 + WO1,
