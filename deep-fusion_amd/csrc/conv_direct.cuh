@@ -48,7 +48,8 @@
 //  * Bank-conflict-free tile pitches (above): 47 % of the LDS cycles at res4 were conflicts; res4 30.2 -> 28.2 us.
 //  * Set-up arithmetic: f32-reciprocal quotients instead of integer division sequences in the staging table and
 //    the per-unit slot decode (~350 instructions per unit).
-// Tried and dropped (A/B logs in profiles/r03/ab_direct_*.txt): priming the conv0 ring before the tile is staged,
+// Tried and dropped (A/B logs in profiles/r03/ab_direct_*.txt): starting the second half of the grid 6-13 k cycles late
+// to de-phase the two workgroups of a CU (slower by the delay), priming the conv0 ring before the tile is staged,
 // conv1 ring depth 4 with PX1 = 2, tile loads one unit ahead, and RASTER units (128 consecutive pixels of the batch
 // across row and image ends, so that every unit is full: 784 instead of 896 units at 28 x 28) -- bit-exact on all
 // shapes, but the taller tile (10 rows instead of 6), its LDS and the per-unit segment table's scalars cost more
