@@ -55,10 +55,13 @@
 // shapes, but the taller tile (10 rows instead of 6), its LDS and the per-unit segment table's scalars cost more
 // than the full units won: res3 44.9 vs 38.5 us on one box, and the extra live scalars slowed the rectangular
 // path by 8-15 % as well (this kernel sits at the SGPR limit: ~100 spilled to VGPR lanes).
-// Where the time goes now (stamps build, profiles/r03/stamps_direct_*.txt): res4 conv0 K loop 45 % (the matrix
-// pipe is 75 % busy inside it), conv1 20 %, tile staging 10 %, store epilogue 9 %, ~5.5 k cycles (9 %) from kernel
-// entry to the first unit.  The weight stream is the floor of res5: 3.4 MB per 32-pixel unit through one CU's L2
-// port at ~44 B/clk.
+//  * 3x3 fast path (T9 below): no scalar bookkeeping in the conv0 K loop -- the generic loop's ~30 scalar
+//    instructions per k-block made res5 (one MFMA per k-block) scalar-issue bound.  res5 43.1 -> 38.1 us, res4
+//    29.9 -> 27.4, res3 35.3 -> 33.1.
+// Where the time goes now (stamps build, profiles/r03/stamps_direct_12_after_fast_path.txt): res4 conv0 K loop 38 %
+// of a unit (the matrix pipe is ~100 % busy inside it), conv1 23 % (77 %), tile staging 11 %, store epilogue 9.5 %,
+// barrier imbalance 8 %; ~5.6 k cycles (10 %) from kernel entry to the first unit.  The weight stream is the floor
+// of res5: 3.4 MB per 32-pixel unit through one CU's L2 port at ~60 B/clk.
 #pragma once
 
 #include "conv_mfma.cuh"
