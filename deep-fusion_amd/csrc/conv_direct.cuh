@@ -91,6 +91,10 @@ struct DirectGeom {
   // but a 32-slot block wraps over 2-5 output rows and the row gap broke the pattern: 47 % of the LDS cycles at
   // res4 were bank conflicts, profiles/r03/final pmc.)
   int row_pitch, img_pitch;
+  // unfused != 0: no 1x1 stage (oc1x1 == 0).  conv0's requantised result IS the output: 4-byte outputs are stored
+  // straight from the accumulators (a lane holds 4 consecutive channels of its pixel per q: one 16-byte store),
+  // 1-byte outputs are collected in `mid` in natural channel order and leave as whole pixel rows (16-byte stores).
+  int unfused;
   int ocb;              // conv0 output blocks, padded to a multiple of WO
   int n_g1;             // conv1 groups of G column blocks
   int mid_stride;       // 32 * ocb + 16
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
   const v16i zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const int ntap = a.kh * a.kw, nkb0 = g.icb * ntap;
   // weights: a.wei = W0d[ocb][nkb0][64 lanes][16 B], a.wei1 = W1d[n_g1][ocb][G][64 lanes][16 B]
-  const unsigned row_bytes = (unsigned)a.oc1 * ESZ;
+  const unsigned row_bytes = (unsigned)(g.unfused ? a.oc : a.oc1) * ESZ;
   const bool fast = g.fast != 0;
   const bool relu1 = a.relu1 || DST == DFX_U8;
   using TT = std::true_type;
@@ -396,6 +400,47 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
     // the ring was drained every 9 k-blocks, 85 cycles per MFMA at res4).  EVEN (nkb0 a multiple of DK_RD, every
     // 3x3 layer): refills run on into the next output block, the requant of one block hides under the loads of
     // the next.  Otherwise whole rounds are branch-free and the last k-blocks of a block run unpipelined.
+    // unfused op: requant 0 IS the output stage (see DirectGeom::unfused)
+    unsigned char *const dst_u = reinterpret_cast<unsigned char *>(a.dst);
+    auto store_unfused = [&](auto fast_tag, int ob, const v16i(&acc)[PXW]) {
+      constexpr bool FAST = decltype(fast_tag)::value;
+#pragma unroll
+      for (int p = 0; p < PXW; ++p) {
+        const int slot = 32 * (wp * PXW + p) + l31;
+        const unsigned off = ESZ == 4 ? pxoff[slot] : 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int ch = ob * 32 + 8 * q + 4 * h;
+          const v4f bs4 = *reinterpret_cast<const v4f *>(bias0 + ch);
+          const v4f sc4 = *reinterpret_cast<const v4f *>(scale0 + ch);
+          if (DST == DFX_U8 && g.m0) {  // "fma" route (accumulators started from the comp slot, bias slot = -2^23 * scale)
+            if constexpr (DST == DFX_U8) {
+              unsigned pk = 0;
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                pk = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(__int_as_float(acc[p][4 * q + i]), sc4[i], bs4[i]), i, pk);
+              *reinterpret_cast<unsigned *>(mid + slot * g.mid_stride + ch) = pk;
+            }
+          } else {
+            int v[4];
+            float bsa[4], sca[4], zf[4];
+            v4i cp4 = {0, 0, 0, 0};
+            if (!FAST) cp4 = *reinterpret_cast<const v4i *>(comp0 + ch);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              v[i] = acc[p][4 * q + i] + cp4[i];
+              bsa[i] = bs4[i]; sca[i] = sc4[i]; zf[i] = 0.0f;
+            }
+            if constexpr (ESZ == 1) {
+              *reinterpret_cast<unsigned *>(mid + slot * g.mid_stride + ch) = pack_group<DST, 4, FAST>(v, zf, bsa, sca, a.relu0 != 0, a.rm0);
+            } else {
+              if (off != 0xffffffffu && ch < a.oc)
+                store_group<DST, 4, FAST>(dst_u + DK_CHK(12, (long long)(off + (unsigned)ch * 4u), 16, g.dst_bytes), v, zf, bsa, sca, a.relu0 != 0, a.rm0);
+            }
+          }
+        }
+      }
+    };
     // T9 (3x3 kernels, DK_RD = 9: one round = the nine taps of one 32-channel input block): the round's loop is
     // free of scalar bookkeeping.  The generic loop tracks (tap, kernel column, input block) and the ring's
     // (output block, k-block) with ~30 scalar instructions per k-block; a SIMD issues about one scalar instruction
@@ -525,7 +570,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
         if constexpr (QM != 0) {
           requant0(std::integral_constant<int, 2>{}, ob, acc);
         } else {
-          if (g.m0) requant0(std::integral_constant<int, 2>{}, ob, acc);
+          if (g.unfused) {
+            if (fast) store_unfused(TT{}, ob, acc); else store_unfused(FF{}, ob, acc);
+          } else if (g.m0) requant0(std::integral_constant<int, 2>{}, ob, acc);
           else if (fast) requant0(std::integral_constant<int, 1>{}, ob, acc);
           else requant0(std::integral_constant<int, 0>{}, ob, acc);
         }
@@ -543,7 +590,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
     // Same scheme: the W1 fragments of this wave are one stream of blocks of G fragments (groups wo1, wo1 + WO1,
     // ...; NP1 passes over each; k-blocks 0 .. ocb - 1) through a ring RD1 blocks deep that is primed BEFORE the
     // barrier and runs on under the store epilogues.
-    const bool has1 = wo1 < g.n_g1;
+    const bool has1 = wo1 < g.n_g1;  // (false for every wave of an unfused op: n_g1 = 0)
     const int g1_last = has1 ? wo1 + (g.n_g1 - 1 - wo1) / WO1 * WO1 : 0;
     int r_g = wo1, r_pp = 0, r_blk = 0;
     auto r1_next = [&]() -> unsigned {
@@ -569,6 +616,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
     __syncthreads();  // mid is complete; the tile is dead (the store staging may use it)
     DFX_STAMP(t5);
     DFX_ACC(3, t5 - t4);  // barrier after conv0
+    if (g.unfused) {
+      if constexpr (ESZ == 1) {  // whole pixel rows of the unit leave `mid`: 16 bytes per lane, a.oc contiguous bytes per pixel
+        const int c16n = a.oc >> 4;
+        const float r_c16 = 1.0f / __int2float_rn(c16n);
+        for (int q = tid; q < 32 * NPB * c16n; q += DK_THREADS) {
+          int c16;
+          const int slot = divmod(q, c16n, r_c16, c16);
+          const unsigned off = pxoff[slot];
+          const v4i val = *reinterpret_cast<const v4i *>(mid + slot * g.mid_stride + 16 * c16);
+          if (off != 0xffffffffu) DFX_STORE16(reinterpret_cast<v4i *>(dst_u + DK_CHK(11, (long long)(off + 16u * c16), 16, g.dst_bytes)), val);
+        }
+      }
+    }
 
     if (has1) {
       v4i fa[2][PX1];

@@ -476,7 +476,8 @@ static bool pick_direct_geometry(const dfx_conv_desc &d, int NW, int WO, int G, 
   const size_t stage_bytes = (G == 4 && dt_size(d.dst_dt) == 1) ? (size_t)NW * DK_STAGE : 0;
   const size_t fixed = 4 * M + (size_t)M * g.mid_stride + cst_bytes;
   const size_t lds_max = 163840;
-  if ((long long)d.bs * d.oh * d.ow * d.oc1x1 * (long long)dt_size(d.dst_dt) >= (1LL << 32) - 16 ||
+  g.unfused = d.oc1x1 == 0 ? 1 : 0;
+  if ((long long)d.bs * d.oh * d.ow * (d.oc1x1 ? d.oc1x1 : d.oc) * (long long)dt_size(d.dst_dt) >= (1LL << 32) - 16 ||
       (long long)d.bs * d.oh * d.ow >= (1LL << 31) || (long long)d.ih * d.iw * d.ic * M >= (1LL << 31))
     return false;
   double best = -1.0;
@@ -773,12 +774,17 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
   // The direct-weight kernel (conv_direct.cuh) serves fused ops with >= 64 channels on both sides wherever one of
   // its instances fits (N=128, u8 out, against conv_stream.cuh: res3 37 vs 50 us, res4 31 vs 53, res5 43 vs 79
   // in two launches, res3s2 45 vs 63: profiles/r03/direct_sweep_*.txt).  DFX_STREAM_DIRECT=0 turns it off.
-  bool want_direct = stream_ok && d.oc1x1 > 0 && d.oc >= 64 && d.oc1x1 >= 64;
-  if (const char *e = tune("DFX_STREAM_DIRECT")) want_direct = stream_ok && d.oc1x1 > 0 && d.oc >= 64 && d.oc1x1 >= 64 && atoi(e) != 0;
+  // Unfused ops (late round 3): the same kernel without its 1x1 stage (DirectGeom::unfused), for convs with a window
+  // (kh * kw > 1) and >= 64 channels on both sides -- VGG conv3 / conv5-style layers.  Pointwise convs stay on
+  // conv_stream.cuh (HBM-bound by their input; measured, profiles/r03/unfused_direct.txt).
+  const bool direct_fused = d.oc1x1 > 0 && d.oc >= 64 && d.oc1x1 >= 64;
+  const bool direct_unfused = d.oc1x1 == 0 && d.oc >= 64 && d.ic >= 64 && d.kh * d.kw > 1 && !d.fuse_pool;
+  bool want_direct = stream_ok && (direct_fused || direct_unfused);
+  if (const char *e = tune("DFX_STREAM_DIRECT")) want_direct = want_direct && atoi(e) != 0;
   if (want_direct) {
     const int ocb2 = ((d.oc + 31) / 32 + 1) / 2 * 2;
     const int ncb1 = (d.oc1x1 + 31) / 32;
-    const int G = ncb1 >= 3 ? 4 : 2;
+    const int G = direct_unfused ? 4 : (ncb1 >= 3 ? 4 : 2);  // (unfused: the instances with G = 4 and no 1x1 groups)
     // Pixel blocks per unit: the largest of 4, 2, 1 whose units still fill three quarters of the workgroup slots
     // (two per CU).  Smaller units re-stream the weights more often, larger ones leave CUs (res4: 196 units of
     // 128 pixels for 512 slots, res5: 64) or SIMDs empty.  With fewer than 4 blocks the four waves split the
@@ -802,7 +808,7 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     struct Cand { int nw, wo, wo1, npb, min_units; };
     std::vector<Cand> cands;
     const int wo4 = ocb2 % 4 == 0 ? 4 : 2;
-    const int wo1_4 = (G == 4 && wo4 == 4 && n_g1 % 4 == 0) ? 4 : 1;
+    const int wo1_4 = (G == 4 && wo4 == 4 && n_g1 % 4 == 0 && !direct_unfused) ? 4 : 1;
     cands.push_back({4, wo4, wo1_4, 4, 3 * ncu2 / 4});
     if (wo1_4 == 4) cands.push_back({4, wo4, 1, 4, 3 * ncu2 / 4});
     if (G == 4 && ocb_real % 8 == 0)
@@ -810,7 +816,11 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     for (int npb : {2, 1}) cands.push_back({4, 4, 4, npb, npb == 1 ? 0 : 3 * ncu2 / 4});
     // first pass: four-wave candidates must also leave room for two workgroups per CU (80 KB of LDS each; a
     // stride-2 layer's 128-pixel halo tile does not: res3s2 72 us with 128-pixel units, 45 us with 64)
-    for (int pass = 0; pass < 2 && !h->direct; ++pass)
+    // ... and every candidate must fill its pixel slots: where the LDS only admits a sliver of a patch (512 input
+    // channels at 14 x 14: 14 x 3 pixels of a 128-slot unit) the next smaller unit is the better kernel (vgg5
+    // unfused: 95 us with 128-slot units, 39 us with 64).  Passes: 0 = all rules, 1 = without the LDS rule,
+    // 2 = anything that fits.
+    for (int pass = 0; pass < 3 && !h->direct; ++pass)
       for (const Cand &c : cands) {
         if (forced && c.npb != forced) continue;
         if (forced_nw && c.nw != forced_nw) continue;
@@ -821,6 +831,11 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
         if (!pick_direct_geometry(d, c.nw, c.wo, G, c.npb, dg, lds)) continue;
         if (!forced && dg.total_units < c.min_units) continue;  // too few units: try the next candidate
         if (!forced && pass == 0 && c.nw == 4 && lds > 81920) continue;
+        const double util = (double)d.bs * d.oh * d.ow / ((double)dg.total_units * 32.0 * c.npb);
+        if (!forced && pass < 2 && util < 0.7) continue;
+        if (tune("DFX_DEBUG_PTRS"))
+          fprintf(stderr, "[dfx] direct candidate nw%d wo%d wo1 %d npb%d: ni %d th %d tw %d units %d (min %d) lds %d pass %d\n", c.nw, c.wo, c.wo1,
+                  c.npb, dg.ni, dg.thv, dg.twv, dg.total_units, c.min_units, lds, pass);
         h->dgeom = dg;
         h->direct = 1;
         h->G = G;
@@ -850,7 +865,8 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     if (const char *e = tune("DFX_STREAM_GRID")) h->grid = std::max(1, std::min(h->grid, atoi(e)));  // testing aid
     a.rows_per_unit = h->dgeom.thv;
     a.units_per_image = h->dgeom.uy * h->dgeom.ux;
-    snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_direct_kernel<nw%d,%d,%d,%d,%d,npb%d>", h->nw, h->wo, h->G, h->wo1, d.dst_dt, h->dgeom.npb);
+    snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_direct_kernel<nw%d,%d,%d,%d,%d,%snpb%d>", h->nw, h->wo, h->G, h->wo1, d.dst_dt,
+             h->dgeom.unfused ? "unfused," : "", h->dgeom.npb);
 #ifdef DFX_STAMPS
     if (hipMalloc((void **)&h->d_prof, (size_t)h->grid * h->nw * 16 * 8) != hipSuccess || hipMemset(h->d_prof, 0, (size_t)h->grid * h->nw * 16 * 8) != hipSuccess) {
       conv_release(h);
@@ -1169,8 +1185,8 @@ static int set_weights_direct(dfx_conv_t *h, const int8_t *wei, const void *bia0
   if (o != n0 + n1) return fail(DFX_ERR_HIP, "internal: direct pack size mismatch");
   std::vector<int32_t> cst((size_t)3 * (OCP + OC1P), 0);
   auto put_f = [&](size_t idx, float v) { memcpy(&cst[idx], &v, 4); };
-  bool fast = d.conv0_round_mode == DFX_ROUND_NEAREST && d.conv1_round_mode == DFX_ROUND_NEAREST;
-  std::vector<float> fb0(OC), fb1(OC1);
+  bool fast = d.conv0_round_mode == DFX_ROUND_NEAREST && (OC1 == 0 || d.conv1_round_mode == DFX_ROUND_NEAREST);
+  std::vector<float> fb0(OC), fb1(OC1 ? OC1 : 1);
   for (int c = 0; c < OC; ++c) {
     int32_t sum = 0, pos = 0, neg = 0;
     for (int ic = 0; ic < IC; ++ic)
@@ -1234,7 +1250,8 @@ static int set_weights_direct(dfx_conv_t *h, const int8_t *wei, const void *bia0
         }
       }
     };
-    bool m0 = true;
+    // (stage 0's "fma" route relies on the unsigned saturation of a u8 result: the fused intermediate, or a u8 dst)
+    bool m0 = OC1 > 0 || d.dst_dt == DFX_U8;
     for (int c = 0; c < OC && m0; ++c) {
       double P, N;
       pn(false, c, P, N);
@@ -1251,7 +1268,7 @@ static int set_weights_direct(dfx_conv_t *h, const int8_t *wei, const void *bia0
       }
       h->dgeom.m0 = 1;
     }
-    bool m1 = d.dst_dt == DFX_U8 && G == 4, fma1 = true;
+    bool m1 = d.dst_dt == DFX_U8 && G == 4 && OC1 > 0, fma1 = true;
     for (int c = 0; c < OC1 && m1; ++c) {
       double P, N;
       pn(true, c, P, N);

@@ -328,6 +328,43 @@ def test_direct_weight_kernel_unit_sizes(hip, oracle, tuning, split, switch):
         hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), name + " " + case.ident())
 
 
+UNFUSED_DIRECT_SHAPES = [
+    C.ConvCase("u64", 3, 64, 12, 10, 64, 0, dst_dt=C.U8),
+    C.ConvCase("u64s8", 2, 64, 9, 20, 64, 0, dst_dt=C.S8, relu0=False, wide=True),
+    C.ConvCase("u128s32", 2, 128, 14, 14, 256, 0, dst_dt=C.S32, per_channel0=True),
+    C.ConvCase("u96f32", 2, 64, 7, 9, 96, 0, dst_dt=C.F32, rm0=1),                      # exact route, 96 = 3 output blocks (padded to WO)
+    C.ConvCase("u256", 3, 256, 14, 14, 256, 0, dst_dt=C.U8, per_channel0=True),        # eight output blocks: the 8-wave forms
+    C.ConvCase("us2", 2, 64, 23, 21, 128, 0, stride=(2, 2), dst_dt=C.U8, wide=True),
+    C.ConvCase("u5x5", 2, 64, 12, 10, 64, 0, k=(5, 5), pad=(2, 2), dst_dt=C.S8),
+    C.ConvCase("unopad", 5, 64, 8, 8, 128, 0, pad=(0, 0), dst_dt=C.U8, bia0_dt=C.UNDEF),
+]
+
+
+@pytest.mark.parametrize("split", ["nw4 wo1=1 npb4", "nw4 wo1=4 npb2", "nw4 wo1=4 npb1", "nw8 wo1=8 npb4", "nw8 wo1=8 npb2", "nw8 wo1=8 npb1"])
+@pytest.mark.parametrize("switch", [None, "DFX_NO_MAGIC", "DFX_NO_FAST"])
+def test_direct_weight_kernel_unfused(hip, oracle, tuning, split, switch):
+    """unfused convs with a window and >= 64 channels on both sides run on conv_direct.cuh without its 1x1 stage
+    (DirectGeom::unfused): 4-byte outputs stored straight from the accumulators, 1-byte outputs collected in LDS in
+    natural channel order and written as whole pixel rows; all dst types, the three requant routes (stage-0 "fma"
+    for u8, fast, exact), every wave / unit split."""
+    nw, wo1, npb = split[2], split.split("wo1=")[1][0], split[-1]
+    tuning.setenv("DFX_DIRECT_NW", nw)
+    tuning.setenv("DFX_DIRECT_WO1", wo1)
+    tuning.setenv("DFX_DIRECT_NPB", npb)
+    if switch:
+        tuning.setenv(switch, "1")
+    ran = 0
+    for case in UNFUSED_DIRECT_SHAPES:
+        data = C.generate(case)
+        got, info = hip.hip_conv(case, data, force_variant=hip.dfa.VARIANT_MFMA_STREAM)
+        name = info.kernel_name.decode()
+        if name.startswith("conv_direct_kernel"):
+            assert "unfused," in name and name.startswith("conv_direct_kernel<nw%s," % nw) and name.endswith("npb%s>" % npb), name
+            ran += 1
+        hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), name + " " + case.ident())
+    assert ran >= (1 if nw == "8" else 4), ran
+
+
 def test_dst_of_4_gib_is_named_in_kernel_name(hip):
     """the streamed- / direct-weight MFMA kernels keep dst offsets in 32 bits: an op whose dst reaches 4 GiB is
     created on the scalar kernel and dfx_conv_query says so (create only: nothing of that size is allocated)"""
