@@ -776,7 +776,7 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
   // in two launches, res3s2 45 vs 63: profiles/r03/direct_sweep_*.txt).  DFX_STREAM_DIRECT=0 turns it off.
   // Unfused ops (late round 3): the same kernel without its 1x1 stage (DirectGeom::unfused), for convs with a window
   // (kh * kw > 1) and >= 64 channels on both sides -- VGG conv3 / conv5-style layers.  Pointwise convs stay on
-  // conv_stream.cuh (HBM-bound by their input; measured, profiles/r03/unfused_direct.txt).
+  // conv_stream.cuh (HBM-bound by their input; pw256 measured here 55 us against 42, profiles/r03/unfused_pointwise.txt).
   const bool direct_fused = d.oc1x1 > 0 && d.oc >= 64 && d.oc1x1 >= 64;
   const bool direct_unfused = d.oc1x1 == 0 && d.oc >= 64 && d.ic >= 64 && d.kh * d.kw > 1 && !d.fuse_pool;
   bool want_direct = stream_ok && (direct_fused || direct_unfused);
