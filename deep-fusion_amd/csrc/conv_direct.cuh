@@ -404,6 +404,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
     unsigned char *const dst_u = reinterpret_cast<unsigned char *>(a.dst);
     auto store_unfused = [&](auto fast_tag, int ob, const v16i(&acc)[PXW]) {
       constexpr bool FAST = decltype(fast_tag)::value;
+      // (a u8 result saturates at 0 whatever the ReLU flag says: the pack helpers take that as relu = true)
+      const bool relu0 = a.relu0 != 0 || DST == DFX_U8;
 #pragma unroll
       for (int p = 0; p < PXW; ++p) {
         const int slot = 32 * (wp * PXW + p) + l31;
@@ -432,10 +434,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
               bsa[i] = bs4[i]; sca[i] = sc4[i]; zf[i] = 0.0f;
             }
             if constexpr (ESZ == 1) {
-              *reinterpret_cast<unsigned *>(mid + slot * g.mid_stride + ch) = pack_group<DST, 4, FAST>(v, zf, bsa, sca, a.relu0 != 0, a.rm0);
+              *reinterpret_cast<unsigned *>(mid + slot * g.mid_stride + ch) = pack_group<DST, 4, FAST>(v, zf, bsa, sca, relu0, a.rm0);
             } else {
               if (off != 0xffffffffu && ch < a.oc)
-                store_group<DST, 4, FAST>(dst_u + DK_CHK(12, (long long)(off + (unsigned)ch * 4u), 16, g.dst_bytes), v, zf, bsa, sca, a.relu0 != 0, a.rm0);
+                store_group<DST, 4, FAST>(dst_u + DK_CHK(12, (long long)(off + (unsigned)ch * 4u), 16, g.dst_bytes), v, zf, bsa, sca, relu0, a.rm0);
             }
           }
         }
