@@ -26,6 +26,7 @@
 #include "conv_mfma.cuh"
 #include "conv_stream.cuh"
 #include "conv_direct.cuh"
+#include "conv_pw.cuh"
 #include "conv_mfma_roles.cuh"
 #include "dfx_device.cuh"
 
@@ -96,7 +97,7 @@ static size_t dt_size(int dt) { return (dt == DFX_F32 || dt == DFX_S32) ? 4 : 1;
 namespace {
 const char *const kTuningKeys[] = {"DFX_MAX_TH", "DFX_FORCE_GEOM", "DFX_STATIC_ROUNDS", "DFX_NO_FAST", "DFX_NO_MAGIC", "DFX_NO_LAZY", "DFX_NO_ROLES", "DFX_STORE_BOUND_BYTES",
                                    "DFX_STREAM_PXB", "DFX_STREAM_BLOCKING", "DFX_STREAM_PLANES", "DFX_STREAM_OCC_PAR",
-                                   "DFX_STREAM_DIRECT", "DFX_DIRECT_NPB", "DFX_DIRECT_NW", "DFX_DIRECT_WO1", "DFX_STREAM_GRID", "DFX_DEBUG_PTRS",
+                                   "DFX_STREAM_DIRECT", "DFX_STREAM_PW", "DFX_DIRECT_NPB", "DFX_DIRECT_NW", "DFX_DIRECT_WO1", "DFX_STREAM_GRID", "DFX_DEBUG_PTRS",
                                    "DEEPFUSION_PROFILE"};
 struct Tuning {
   std::mutex mu;
@@ -148,6 +149,8 @@ struct dfx_conv {
   StreamGeom sgeom;  // DFX_VARIANT_MFMA_STREAM
   DirectGeom dgeom;  // DFX_VARIANT_MFMA_STREAM served by conv_direct.cuh (fused ops): direct != 0
   int direct, nw, wo, wo1;
+  int pw;            // DFX_VARIANT_MFMA_STREAM served by conv_pw.cuh (pointwise unfused): direct != 0 too (weights packed as for conv_direct.cuh)
+  PwGeom pwgeom;
   int occ, pxb;      // stream variant: conv0 output blocks per chunk, pixel blocks per wave
   int icb, ocb, G, grid, block, lds;
   // role-specialised fused kernel (conv_mfma_roles.cuh): roles_ok = the SHAPE fits it (decided at create; LDS is
@@ -552,7 +555,15 @@ static bool pick_direct_geometry(const dfx_conv_desc &d, int NW, int WO, int G, 
   return true;
 }
 
+namespace dfx { int launch_conv_pw(const ConvArgs &, const PwGeom &, int, int, int, hipStream_t, int); }
+
 static int direct_dispatch(dfx_conv *h, const ConvArgs &a, hipStream_t s, int mode) {
+  if (h->pw) {  // pointwise unfused conv (conv_pw.cuh); the requant proofs live in dgeom (set_weights_direct)
+    PwGeom pg = h->pwgeom;
+    pg.fast = h->dgeom.fast;
+    pg.m0 = h->dgeom.m0;
+    return dfx::launch_conv_pw(a, pg, h->d.dst_dt, h->grid, h->lds, s, mode);
+  }
   switch (h->d.dst_dt) {
     case DFX_F32: return launch_conv_direct_f32(a, h->dgeom, h->nw, h->wo, h->G, h->wo1, h->grid, h->lds, s, mode);
     case DFX_S32: return launch_conv_direct_s32(a, h->dgeom, h->nw, h->wo, h->G, h->wo1, h->grid, h->lds, s, mode);
@@ -779,7 +790,36 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
   // conv_stream.cuh (HBM-bound by their input; pw256 measured here 55 us against 42, profiles/r03/unfused_pointwise.txt).
   const bool direct_fused = d.oc1x1 > 0 && d.oc >= 64 && d.oc1x1 >= 64;
   const bool direct_unfused = d.oc1x1 == 0 && d.oc >= 64 && d.ic >= 64 && d.kh * d.kw > 1 && !d.fuse_pool;
-  bool want_direct = stream_ok && (direct_fused || direct_unfused);
+  // Pointwise unfused convs whose weights fit LDS: conv_pw.cuh (pixel fragments straight from global memory into the
+  // MFMA operands, no input tile).  DFX_STREAM_PW=0 turns it off (those shapes then run on conv_stream.cuh).
+  bool want_pw = stream_ok && d.oc1x1 == 0 && d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.pad_t == 0 && d.pad_l == 0 &&
+                 !d.fuse_pool && d.ic % 256 == 0 && (d.oc == 64 || d.oc == 128 || d.oc == 256) && (long long)d.oc * d.ic <= 98304 &&
+                 (long long)d.bs * d.oh * d.ow < (1LL << 31) - 64;
+  if (const char *e = tune("DFX_STREAM_PW")) want_pw = want_pw && atoi(e) != 0;
+  if (want_pw) {
+    memset(&h->dgeom, 0, sizeof(h->dgeom));
+    h->dgeom.icb = d.ic / 32;
+    h->dgeom.ocb = d.oc / 32;
+    h->dgeom.n_g1 = 0;
+    h->dgeom.unfused = 1;
+    h->dgeom.npb = 1;
+    h->G = 4;
+    h->pw = 1;
+    h->direct = 1;
+    h->nw = PW_THREADS / 64;
+    h->pwgeom.icb = h->dgeom.icb;
+    h->pwgeom.ocb = h->dgeom.ocb;
+    h->pwgeom.px_total = d.bs * d.oh * d.ow;
+    h->pwgeom.n_blocks = (h->pwgeom.px_total + 31) / 32;
+    h->pwgeom.off_cst = d.oc * d.ic;
+    h->pwgeom.fast = h->pwgeom.m0 = 0;
+    h->pwgeom.off_stage = (int)round16((size_t)d.oc * d.ic + (size_t)3 * d.oc * 4);
+    h->pwgeom.stage_bytes = (int)round16(dt_size(d.dst_dt) == 1 ? (size_t)32 * (d.oc + 16) : (size_t)32 * 144);
+    h->lds = h->pwgeom.off_stage + h->nw * h->pwgeom.stage_bytes;
+    h->dgeom.total_units = (h->pwgeom.n_blocks + h->nw - 1) / h->nw;  // (workgroups' worth of blocks: the grid's upper bound)
+    h->dgeom.thv = 0; h->dgeom.uy = h->dgeom.ux = 1;
+  }
+  bool want_direct = stream_ok && !h->pw && (direct_fused || direct_unfused);
   if (const char *e = tune("DFX_STREAM_DIRECT")) want_direct = want_direct && atoi(e) != 0;
   if (want_direct) {
     const int ocb2 = ((d.oc + 31) / 32 + 1) / 2 * 2;
@@ -865,8 +905,11 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     if (const char *e = tune("DFX_STREAM_GRID")) h->grid = std::max(1, std::min(h->grid, atoi(e)));  // testing aid
     a.rows_per_unit = h->dgeom.thv;
     a.units_per_image = h->dgeom.uy * h->dgeom.ux;
-    snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_direct_kernel<nw%d,%d,%d,%d,%d,%snpb%d>", h->nw, h->wo, h->G, h->wo1, d.dst_dt,
-             h->dgeom.unfused ? "unfused," : "", h->dgeom.npb);
+    if (h->pw)
+      snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_pw_kernel<%d,%d>", h->dgeom.ocb, d.dst_dt);
+    else
+      snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_direct_kernel<nw%d,%d,%d,%d,%d,%snpb%d>", h->nw, h->wo, h->G, h->wo1, d.dst_dt,
+               h->dgeom.unfused ? "unfused," : "", h->dgeom.npb);
 #ifdef DFX_STAMPS
     if (hipMalloc((void **)&h->d_prof, (size_t)h->grid * h->nw * 16 * 8) != hipSuccess || hipMemset(h->d_prof, 0, (size_t)h->grid * h->nw * 16 * 8) != hipSuccess) {
       conv_release(h);

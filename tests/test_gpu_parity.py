@@ -367,6 +367,38 @@ def test_direct_weight_kernel_unfused(hip, oracle, tuning, split, switch):
     assert ran >= (1 if nw == "8" else 4), ran
 
 
+PW_SHAPES = [
+    C.ConvCase("pw256_64", 3, 256, 9, 11, 64, 0, k=(1, 1), pad=(0, 0), dst_dt=C.U8),                    # 297 px: partial last block
+    C.ConvCase("pw512_128", 2, 512, 7, 7, 128, 0, k=(1, 1), pad=(0, 0), dst_dt=C.S8, relu0=False, wide=True),
+    C.ConvCase("pw256_256", 2, 256, 5, 13, 256, 0, k=(1, 1), pad=(0, 0), dst_dt=C.S32, per_channel0=True),
+    C.ConvCase("pw768_64", 1, 768, 6, 6, 64, 0, k=(1, 1), pad=(0, 0), dst_dt=C.F32, rm0=1),
+    C.ConvCase("pw256_128", 5, 256, 4, 4, 128, 0, k=(1, 1), pad=(0, 0), dst_dt=C.U8, relu0=False, rm0=1, bia0_dt=C.S8),
+    C.ConvCase("pw1px", 1, 256, 1, 1, 64, 0, k=(1, 1), pad=(0, 0), dst_dt=C.U8),                          # one pixel
+    C.ConvCase("pw_many", 2, 256, 40, 37, 64, 0, k=(1, 1), pad=(0, 0), dst_dt=C.U8, bia0_dt=C.UNDEF),    # more blocks than waves
+]
+
+
+@pytest.mark.parametrize("switch", [None, "DFX_NO_MAGIC", "DFX_NO_FAST"])
+def test_pointwise_kernel(hip, oracle, tuning, switch):
+    """unfused 1x1 stride-1 convs whose weights fit LDS (ic a multiple of 256, oc 64 / 128 / 256) run on conv_pw.cuh:
+    pixel fragments straight from global memory into the MFMA operands; all dst types, the three requant routes;
+    DFX_STREAM_PW=0 sends the same shapes to conv_stream.cuh."""
+    if switch:
+        tuning.setenv(switch, "1")
+    for case in PW_SHAPES:
+        data = C.generate(case)
+        ref = hip.oracle_conv(oracle, case, data)
+        got, info = hip.hip_conv(case, data)
+        assert info.kernel_name.decode().startswith("conv_pw_kernel"), info.kernel_name
+        hip.assert_bit_equal(got, ref, info.kernel_name.decode() + " " + case.ident())
+    tuning.setenv("DFX_STREAM_PW", "0")
+    case = PW_SHAPES[0]
+    data = C.generate(case)
+    got, info = hip.hip_conv(case, data)
+    assert info.kernel_name.decode().startswith("conv_stream_kernel"), info.kernel_name
+    hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), info.kernel_name.decode())
+
+
 def test_dst_of_4_gib_is_named_in_kernel_name(hip):
     """the streamed- / direct-weight MFMA kernels keep dst offsets in 32 bits: an op whose dst reaches 4 GiB is
     created on the scalar kernel and dfx_conv_query says so (create only: nothing of that size is allocated)"""
