@@ -65,6 +65,7 @@
 #pragma once
 
 #include "conv_mfma.cuh"
+#include "conv_pw.cuh"  // pw_quarter: one quarter block after requant, as values
 
 namespace dfx {
 
@@ -406,39 +407,41 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
       constexpr bool FAST = decltype(fast_tag)::value;
       // (a u8 result saturates at 0 whatever the ReLU flag says: the pack helpers take that as relu = true)
       const bool relu0 = a.relu0 != 0 || DST == DFX_U8;
+      const bool fma0 = DST == DFX_U8 && g.m0 != 0;  // "fma" route (accumulators started from the comp slot, bias slot = -2^23 * scale)
 #pragma unroll
       for (int p = 0; p < PXW; ++p) {
-        const int slot = 32 * (wp * PXW + p) + l31;
-        const unsigned off = ESZ == 4 ? pxoff[slot] : 0u;
+        const int slot0 = 32 * (wp * PXW + p);
+        v4i qv[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int ch = ob * 32 + 8 * q + 4 * h;
           const v4f bs4 = *reinterpret_cast<const v4f *>(bias0 + ch);
           const v4f sc4 = *reinterpret_cast<const v4f *>(scale0 + ch);
-          if (DST == DFX_U8 && g.m0) {  // "fma" route (accumulators started from the comp slot, bias slot = -2^23 * scale)
-            if constexpr (DST == DFX_U8) {
-              unsigned pk = 0;
+          v4i cp4 = {0, 0, 0, 0};
+          if (!FAST) cp4 = *reinterpret_cast<const v4i *>(comp0 + ch);
+          int a4[4];
 #pragma unroll
-              for (int i = 0; i < 4; ++i)
-                pk = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(__int_as_float(acc[p][4 * q + i]), sc4[i], bs4[i]), i, pk);
-              *reinterpret_cast<unsigned *>(mid + slot * g.mid_stride + ch) = pk;
-            }
-          } else {
-            int v[4];
-            float bsa[4], sca[4], zf[4];
-            v4i cp4 = {0, 0, 0, 0};
-            if (!FAST) cp4 = *reinterpret_cast<const v4i *>(comp0 + ch);
+          for (int i = 0; i < 4; ++i) a4[i] = acc[p][4 * q + i];
+          qv[q] = pw_quarter<DST, FAST>(a4, cp4, bs4, sc4, relu0, a.rm0, fma0);
+        }
+        if constexpr (ESZ == 1) {  // natural channel order in `mid`; the rows leave after the barrier
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              v[i] = acc[p][4 * q + i] + cp4[i];
-              bsa[i] = bs4[i]; sca[i] = sc4[i]; zf[i] = 0.0f;
-            }
-            if constexpr (ESZ == 1) {
-              *reinterpret_cast<unsigned *>(mid + slot * g.mid_stride + ch) = pack_group<DST, 4, FAST>(v, zf, bsa, sca, relu0, a.rm0);
-            } else {
-              if (off != 0xffffffffu && ch < a.oc)
-                store_group<DST, 4, FAST>(dst_u + DK_CHK(12, (long long)(off + (unsigned)ch * 4u), 16, g.dst_bytes), v, zf, bsa, sca, relu0, a.rm0);
-            }
+          for (int q = 0; q < 4; ++q) *reinterpret_cast<int *>(mid + (slot0 + l31) * g.mid_stride + ob * 32 + 8 * q + 4 * h) = qv[q][0];
+        } else {
+          // 4-byte outputs: this block's 32 px x 128 B through a wave-private piece of the (otherwise unused) mid
+          // area, then 16 bytes per lane: eight lanes write one pixel's 128 contiguous bytes.  (Stored straight from
+          // the accumulators -- 32-byte pieces, four instructions per line -- vgg3 s32 took 197 us against 174 on
+          // conv_stream.cuh.)
+          unsigned char *stg4 = mid + wave * (32 * 144);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *reinterpret_cast<v4i *>(stg4 + l31 * 144 + 32 * q + 16 * h) = qv[q];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int ck = lane + 64 * k, row = ck >> 3, c16 = ck & 7;
+            const unsigned off = pxoff[slot0 + row];
+            const v4i val = *reinterpret_cast<const v4i *>(stg4 + row * 144 + 16 * c16);
+            if (off != 0xffffffffu && ob * 32 + 4 * c16 < a.oc)
+              DFX_STORE16(reinterpret_cast<v4i *>(dst_u + DK_CHK(12, (long long)(off + (unsigned)(ob * 128 + 16 * c16)), 16, g.dst_bytes)), val);
           }
         }
       }
