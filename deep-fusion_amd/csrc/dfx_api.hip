@@ -471,7 +471,7 @@ static bool pick_direct_geometry(const dfx_conv_desc &d, int NW, int WO, int G, 
   const int ocb_real = (d.oc + 31) / 32;
   g.icb = (d.ic + 31) / 32;
   g.n_planes = (g.icb + 1) / 2;
-  if (g.n_planes > 15) return false;  // (packed into 4 bits in the staging table)
+  if (g.n_planes > 16) return false;  // (plane index 0..15: 4 bits in the staging table)
   g.ocb = (ocb_real + WO - 1) / WO * WO;
   g.n_g1 = ((d.oc1x1 + 31) / 32 + G - 1) / G;
   g.mid_stride = 32 * g.ocb + 16;
@@ -791,7 +791,9 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
   // (kh * kw > 1) and >= 64 channels on both sides -- VGG conv3 / conv5-style layers.  Pointwise convs stay on
   // conv_stream.cuh (HBM-bound by their input; pw256 measured here 55 us against 42, profiles/r03/unfused_pointwise.txt).
   const bool direct_fused = d.oc1x1 > 0 && d.oc >= 64 && d.oc1x1 >= 64;
-  const bool direct_unfused = d.oc1x1 == 0 && d.oc >= 64 && d.ic >= 64 && d.kh * d.kw > 1 && !d.fuse_pool;
+  // ... except deep ones whose weights do not fit conv_pw.cuh's LDS image (ic >= 512: res4 / res5 reduce convs, 1024 ->
+  // 256 at 14 x 14: 26.8 us here against 31.3, profiles/r03/unfused_pointwise.txt).
+  const bool direct_unfused = d.oc1x1 == 0 && d.oc >= 64 && d.ic >= 64 && (d.kh * d.kw > 1 || d.ic >= 512) && !d.fuse_pool;
   // Pointwise unfused convs whose weights fit LDS: conv_pw.cuh (pixel fragments straight from global memory into the
   // MFMA operands, no input tile).  DFX_STREAM_PW=0 turns it off (those shapes then run on conv_stream.cuh).
   bool want_pw = stream_ok && d.oc1x1 == 0 && d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.pad_t == 0 && d.pad_l == 0 &&
@@ -853,8 +855,11 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     const int wo1_4 = (G == 4 && wo4 == 4 && n_g1 % 4 == 0 && !direct_unfused) ? 4 : 1;
     cands.push_back({4, wo4, wo1_4, 4, 3 * ncu2 / 4});
     if (wo1_4 == 4) cands.push_back({4, wo4, 1, 4, 3 * ncu2 / 4});
-    if (G == 4 && ocb_real % 8 == 0)
+    if (G == 4 && ocb_real % 8 == 0) {
+      // (a pointwise conv's units are short -- one tap -- and 64-pixel units measured better than 128: tried first)
+      if (direct_unfused && d.kh * d.kw == 1) cands.push_back({8, 8, 8, 2, 3 * ncu2 / 8});
       for (int npb : {4, 2, 1}) cands.push_back({8, 8, 8, npb, npb == 1 ? 0 : 3 * ncu2 / 8});
+    }
     for (int npb : {2, 1}) cands.push_back({4, 4, 4, npb, npb == 1 ? 0 : 3 * ncu2 / 4});
     // first pass: four-wave candidates must also leave room for two workgroups per CU (80 KB of LDS each; a
     // stride-2 layer's 128-pixel halo tile does not: res3s2 72 us with 128-pixel units, 45 us with 64)

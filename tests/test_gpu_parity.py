@@ -337,6 +337,9 @@ UNFUSED_DIRECT_SHAPES = [
     C.ConvCase("us2", 2, 64, 23, 21, 128, 0, stride=(2, 2), dst_dt=C.U8, wide=True),
     C.ConvCase("u5x5", 2, 64, 12, 10, 64, 0, k=(5, 5), pad=(2, 2), dst_dt=C.S8),
     C.ConvCase("unopad", 5, 64, 8, 8, 128, 0, pad=(0, 0), dst_dt=C.U8, bia0_dt=C.UNDEF),
+    # deep pointwise convs whose weights do not fit conv_pw.cuh's LDS image: 16 input planes, the most the staging table holds
+    C.ConvCase("upw1024", 3, 1024, 5, 5, 256, 0, k=(1, 1), pad=(0, 0), dst_dt=C.U8),
+    C.ConvCase("upw512s32", 2, 512, 6, 7, 256, 0, k=(1, 1), pad=(0, 0), dst_dt=C.S32, relu0=False),
     # u8 dst without ReLU on the exact route (round-down): negative results saturate at 0 (found by profiles/debug/soak_random.py)
     C.ConvCase("u8norelu", 21, 192, 4, 3, 512, 0, k=(3, 2), stride=(1, 2), pad=(1, 1), dst_dt=C.U8, bia0_dt=C.S8, relu0=False, rm0=1),
 ]
