@@ -931,7 +931,7 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
     }
     h->dgeom.dbg = (long long *)h->d_prof;
     h->dgeom.src_bytes = (long long)d.bs * d.ih * d.iw * d.ic;
-    h->dgeom.dst_bytes = (long long)d.bs * d.oh * d.ow * d.oc1x1 * (long long)dt_size(d.dst_dt);
+    h->dgeom.dst_bytes = (long long)d.bs * d.oh * d.ow * (d.oc1x1 ? d.oc1x1 : d.oc) * (long long)dt_size(d.dst_dt);
 #endif
   } else if (stream_ok) {
     h->variant = DFX_VARIANT_MFMA_STREAM;
