@@ -491,6 +491,12 @@ def bench_u8_out(torch, hipref, C, case, data, args, world, dist, rank):
             "images_per_sec_per_gpu": round(case.bs / (kern_ms * 1e-3), 1),
             "algorithmic_ops_per_launch": ops, "algorithmic_bytes_per_launch": byts,
             "hbm_GBps": round(gbs, 2), "hbm_frac_of_8TBps": round(gbs / HBM_PEAK_GBS, 4),
+            # which roof binds this op: the larger of the two floor times.  With 1-byte output the block moves
+            # 128.5 MB for 42.7 GOP = 333 op/B, below the ridge (int8 peak / HBM peak = 629 op/B): the HBM floor
+            # is the higher one, and 40 % of the int8 peak would be 76 % of the HBM peak
+            "floors_us": {"hbm": round(byts / (HBM_PEAK_GBS * 1e9) * 1e6, 2),
+                          "mfma": round(ops / (INT8_PEAK_TOPS * 1e12) * 1e6, 2)},
+            "binding_roof": "hbm" if byts / (HBM_PEAK_GBS * 1e9) > ops / (INT8_PEAK_TOPS * 1e12) else "mfma",
             "checked": checked}
 
 

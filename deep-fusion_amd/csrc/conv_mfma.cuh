@@ -613,11 +613,11 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
                                       : (int)blockIdx.x;
   auto stream_id = [&](int tm) { return tm * (int)gridDim.x + wg; };
   const bool coop0 = g.static_rounds >= 1;
-  // coop1: each loader stages its second unit (static as well) into slot 2 + team BEFORE the barrier,
-  // while the compute waves copy the weights: all four slots are full when the claim loop starts.
-  // (Staged after the barrier it was published ~17 k cycles into the loop -- the loader's first pass
-  // through its code is slow -- and half the compute waves sat idle that long: profiles/stamps.py timeline.)
-  const bool coop1 = g.static_rounds >= 2;
+  // (Rounds 1-3 staged every stream's SECOND unit before the barrier as well -- static_rounds >= 2 -- so that all
+  // four slots were full when the claim loop started.  But then the whole chip pulls four units per CU from HBM at
+  // once and every workgroup waits for all of it; with the loader fetching its second unit behind the barrier like
+  // every later one the barrier is passed ~3.7 k cycles earlier and the headline launches are 0.6-0.8 us shorter:
+  // profiles/r03/ab_s32_second_unit.txt, and conv_mfma_roles.cuh's loader for what else was tried.)
 
   // LDS control words are read and written by WHOLE waves (every lane the same word, the same
   // value) and every loaded value goes through readfirstlane, so that all control flow below is
@@ -698,10 +698,10 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
         if (coop0 && stream_id(ctid - CTL_END) >= g.total_units) v = ctid - CTL_END;
       }
       // slot sl starts out published when its unit is staged before the barrier: slots 0, 1 by the
-      // compute waves (coop0), slots 2, 3 by the loaders themselves (coop1: their second unit is static too)
+      // compute waves (coop0); slots 2, 3 are published by the loaders behind the barrier
       auto first_unit = [&](int sl) {
         const int u = (sl >> 1) * (int)gridDim.x * MFMA_TEAMS + stream_id(sl & 1);
-        return (sl < 2 ? coop0 : coop1) && u < g.total_units ? u : -1;
+        return sl < 2 && coop0 && u < g.total_units ? u : -1;
       };
       if (ctid >= CTL_FULL && ctid < CTL_FULL + MFMA_NB && first_unit(ctid - CTL_FULL) >= 0) v = 1;
       if (ctid >= CTL_INFO && ctid < CTL_INFO + 4 * MFMA_NB) {
@@ -826,6 +826,9 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
       }
     };
     auto write_rest = [&](unsigned char *ins, int unit) {  // oversized tile: the rest is staged synchronously
+      // (one granule per trip.  Eight loads in flight per trip -- 32 more live VGPRs in this wave -- cost the u8
+      // headline 4.5 us, the s32 one 3.5 us and VGG f32 40 %, although only the last takes this path at all:
+      // profiles/r03/ab_loader_rest_batched.txt)
       if (g.tile_chunks > 64 * MFMA_LC) {
         const uint8_t *src_n; int y0, x0;
         unit_origin(unit, src_n, y0, x0);
@@ -834,15 +837,7 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
       }
     };
     DFX_STAMP(l_pre);
-    int j0 = coop0 ? 1 : 0;
-    if (coop1 && T + tg < g.total_units) {  // (its unit record and FULL flag: see the control block above)
-      const int u1 = T + tg;
-      unsigned char *ins1 = tiles + (size_t)(2 + team) * g.tile_stride;
-      DFX_PREFETCH(u1);
-      write_tile(ins1);
-      write_rest(ins1, u1);
-      j0 = 2;
-    }
+    const int j0 = coop0 ? 1 : 0;
     if (coop0) __syncthreads();
     // lazy: store-bound ops, whose workgroups run at very different speeds (their share of the HBM write
     // bandwidth: lifetimes 100 k .. 206 k cycles on the s32 headline).  Drawing ahead -- two units per

@@ -217,7 +217,6 @@ __global__ __launch_bounds__(RL_THREADS, (RL_WAVES + 3) / 4) void conv_mfma_role
   };
   auto stream_id = [&](int tm) { return tm * (int)gridDim.x + wg; };
   const bool coop0 = g.static_rounds >= 1;
-  const bool coop1 = g.static_rounds >= 2;
   auto ctl_load = [&](int idx) {
     return __builtin_amdgcn_readfirstlane(
         __hip_atomic_load(ctrl + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -310,6 +309,9 @@ __global__ __launch_bounds__(RL_THREADS, (RL_WAVES + 3) / 4) void conv_mfma_role
       }
     };
     auto write_rest = [&](unsigned char *ins, int unit) {
+      // (one granule per trip.  Eight loads in flight per trip -- 32 more live VGPRs in this wave -- cost the u8
+      // headline 4.5 us, the s32 one 3.5 us and VGG f32 40 %, although only the last takes this path at all:
+      // profiles/r03/ab_loader_rest_batched.txt)
       if (g.tile_chunks > 64 * MFMA_LC) {
         const uint8_t *src_n; int y0, x0;
         unit_origin(unit, src_n, y0, x0);
@@ -317,9 +319,18 @@ __global__ __launch_bounds__(RL_THREADS, (RL_WAVES + 3) / 4) void conv_mfma_role
           *reinterpret_cast<v4i *>(ins + 16 * q) = load_granule(src_n, y0, x0, q);
       }
     };
-    int j0 = coop0 ? 1 : 0;
-    if (coop1 && T + tg < g.total_units) j0 = 2;  // (its second unit is staged by the compute waves too, see there)
-    RL_ADD(8, dfx_stamp() - t_entry);  // entry -> second unit staged (reaches the barrier)
+    const int j0 = coop0 ? 1 : 0;
+    // The stream's second unit is fetched here, behind the barrier, like every later one.  History (stamps, cycles
+    // after entry, headline block): staged before the barrier -- by the loader (round 2) or by the compute waves
+    // next to the first units (most of round 3) -- all of the chip's CUs pull 4 units each from HBM at once: the
+    // first units arrive after 6.2 k cycles and the workgroup passes the barrier after 9.4 k; fetched behind the
+    // barrier, the first units are there after 3.9 k, the barrier is passed after 5.7 k, and the second units are
+    // published ~1.3 k cycles after the A waves ran out of first-unit tiles: 28.6 -> 27.9 us
+    // (profiles/r03/ab_roles_second_unit.txt).  Issuing these loads BEFORE the barrier and passing it with them in
+    // flight (a bare s_barrier) -- timed by a probe load of the first unit's last bytes, or behind a warm-up pass of
+    // the prefetch code over the first unit -- made the loader the last wave at the barrier (6.8 k, 8.1 k): its first
+    // pass through this code is slow wherever it runs (same file: no gain over staging before the barrier).
+    RL_ADD(8, dfx_stamp() - t_entry);  // entry -> reaches the barrier
     if (coop0) __syncthreads();
     RL_ADD(9, dfx_stamp() - t_entry);  // entry -> past the barrier
     const bool lazy = use_queue && g.lazy_queue;
@@ -413,44 +424,23 @@ __global__ __launch_bounds__(RL_THREADS, (RL_WAVES + 3) / 4) void conv_mfma_role
         if (q < total && (q < w1_first || q >= w1_end))
           __builtin_amdgcn_global_load_lds((global_void *)(s + q), (lds_void *)(d + 64 * j), 16, 0, 0);
       }
-      // The first TWO units of stream `steam` (both static: coop0 / coop1): all their global loads are issued
-      // before the first LDS write.  (Tried late in round 3: waiting only for W0 + the first units at the barrier and
-      // writing the second units behind it -- the barrier moved from 8.6 k to 7.4 k cycles after entry in the
-      // stamps build, the launch time did not move: 28.8-29.6 us both ways, profiles/r03/ab_roles_defer_second_units.txt.)  (Until round 3 the loader staged its second unit itself before the barrier:
-      // its table set-up put those loads ~3 k cycles behind everybody else's and the whole workgroup waited at the
-      // barrier for them -- stamps: compute waves there after 4.6-5.9 k cycles, loaders after 6.9 k.)
-      constexpr int NTL = 4;  // 16-byte chunks per thread and unit held in registers at once
-      const int unit1 = (int)gridDim.x * MFMA_TEAMS + unit0;
-      const bool tile1 = coop1 && unit1 < g.total_units;
-      unsigned char *slot1 = tiles + (size_t)(2 + steam) * g.tile_stride;
-      const uint8_t *src_n1 = a.src;
-      int y1 = 0, x1 = 0;
-      if (tile1) unit_origin(unit1, src_n1, y1, x1);
-      v4i tv[NTL], tw[NTL];
+      // The first unit of stream `steam`: all its global loads are issued before the first LDS write.  (The
+      // stream's SECOND unit is the loader's, see there.  Earlier versions staged it here as well, in the same memory
+      // round trip: the workgroup then waits at the barrier for twice the bytes while the whole chip is pulling
+      // its first units from HBM -- barrier passed 9.4 k cycles after entry instead of 5.7 k.  Waiting only for W0 +
+      // the first units at the barrier and writing the second units behind it did not help either: the loads still
+      // compete, profiles/r03/ab_roles_defer_second_units.txt.)
+      constexpr int NTL = 4;  // 16-byte chunks per thread held in registers at once
+      v4i tv[NTL];
       if (tile0) {
 #pragma unroll
         for (int i = 0; i < NTL; ++i) tv[i] = load_granule(src_n, y0, x0, min(tctid + i * TT, g.tile_chunks - 1));
-      }
-      if (tile1) {
-#pragma unroll
-        for (int i = 0; i < NTL; ++i) tw[i] = load_granule(src_n1, y1, x1, min(tctid + i * TT, g.tile_chunks - 1));
-      }
-      if (tile0) {
 #pragma unroll
         for (int i = 0; i < NTL; ++i)
           if (tctid + i * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot + 16 * (tctid + i * TT)) = tv[i];
-      }
-      if (tile1) {
-#pragma unroll
-        for (int i = 0; i < NTL; ++i)
-          if (tctid + i * TT < g.tile_chunks) *reinterpret_cast<v4i *>(slot1 + 16 * (tctid + i * TT)) = tw[i];
-      }
-      if (tile0)
         for (int q = tctid + NTL * TT; q < g.tile_chunks; q += TT)
           *reinterpret_cast<v4i *>(slot + 16 * q) = load_granule(src_n, y0, x0, q);
-      if (tile1)
-        for (int q = tctid + NTL * TT; q < g.tile_chunks; q += TT)
-          *reinterpret_cast<v4i *>(slot1 + 16 * q) = load_granule(src_n1, y1, x1, q);
+      }
 #ifdef DFX_STAMPS
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       RL_ADD(7, dfx_stamp() - t_entry);  // entry -> staged global loads have arrived
@@ -464,7 +454,7 @@ __global__ __launch_bounds__(RL_THREADS, (RL_WAVES + 3) / 4) void conv_mfma_role
       }
       auto first_unit = [&](int sl) {
         const int u = (sl >> 1) * (int)gridDim.x * MFMA_TEAMS + stream_id(sl & 1);
-        return (sl < 2 ? coop0 : coop1) && u < g.total_units ? u : -1;
+        return sl < 2 && coop0 && u < g.total_units ? u : -1;
       };
       if (ctid >= CTL_INFO && ctid < CTL_INFO + 4 * MFMA_NB) {  // slots staged before the barrier start out published
         const int u0 = first_unit((ctid - CTL_INFO) >> 2);

@@ -12,7 +12,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 capi = importlib.import_module("deep-fusion_amd.capi")
-capi._LIB = os.path.join(ROOT, "deep-fusion_amd", "libdfx_hip_stamps.so")
+capi._LIB = os.environ.get("DFX_STAMPS_LIB") or os.path.join(ROOT, "deep-fusion_amd", "libdfx_hip_stamps.so")
 import torch  # noqa: E402
 import cases as C  # noqa: E402
 import hipref  # noqa: E402
