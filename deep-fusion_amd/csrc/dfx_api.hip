@@ -459,8 +459,10 @@ static bool mfma_eligible(const dfx_conv_desc &d) {  // fused or unfused (oc1x1 
 // the role-specialised kernel (conv_mfma_roles.cuh): fused, 1-byte output, output channels in groups of 128 (<= 4)
 static bool roles_eligible(const dfx_conv_desc &d) {
   if (tune("DFX_NO_ROLES") && atoi(tune("DFX_NO_ROLES")) != 0) return false;  // testing aid: conv_mfma.cuh's kernel
+  // (must mirror DFX_FOR_EACH_ROLES_SHAPE in conv_mfma_roles_inst.inc: with oc = 64 only oc1x1 <= 256 is built --
+  //  admitting 384 / 512 here made dfx_conv_create fail for those ops, found by profiles/debug/soak_resident.py)
   return mfma_eligible(d) && d.oc1x1 > 0 && !d.fuse_pool && (d.dst_dt == DFX_U8 || d.dst_dt == DFX_S8) &&
-         d.oc1x1 % 128 == 0 && d.oc1x1 / 128 <= 4;
+         d.oc1x1 % 128 == 0 && d.oc1x1 / 128 <= (d.oc == 64 ? 2 : 4);
 }
 
 // ---- direct-weight fused kernel (conv_direct.cuh) ----

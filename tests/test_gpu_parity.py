@@ -915,6 +915,22 @@ def test_role_specialised_kernel_falls_back(hip, oracle, tuning):
         hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), "fallback")
         if sw:
             tuning.setenv(sw, None)
+    # shapes the role-specialised kernel is not built for (oc = 64 with oc1x1 = 384 / 512): create must succeed
+    # and serve them with conv_mfma.cuh's kernel (dfx_conv_create failed for them until late in round 3)
+    for ic, oc1 in ((64, 384), (32, 512), (64, 512)):
+        for dt in (C.U8, C.S8):
+            case = C.ConvCase("noroles", 2, ic, 13, 17, 64, oc1, dst_dt=dt)
+            data = C.generate(case)
+            got, info = hip.hip_conv(case, data)
+            assert info.kernel_name.decode().startswith("conv_mfma_fused_kernel"), info.kernel_name
+            hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), "no roles instance")
+    # ... and the largest ones it is built for
+    for ic, oc, oc1 in ((64, 64, 256), (32, 64, 256), (64, 32, 512), (32, 32, 384)):
+        case = C.ConvCase("roles", 2, ic, 13, 17, oc, oc1, dst_dt=C.U8)
+        data = C.generate(case)
+        got, info = hip.hip_conv(case, data)
+        assert info.kernel_name.decode().startswith("conv_mfma_roles_kernel"), info.kernel_name
+        hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), "roles instance")
     data = C.generate(base)
     data["scales0"] = -data["scales0"]          # negative scale: the fma mode's sign argument does not hold
     got, info = hip.hip_conv(base, data)
