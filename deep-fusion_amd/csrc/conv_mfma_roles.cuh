@@ -553,11 +553,14 @@ __global__ __launch_bounds__(RL_THREADS, (RL_WAVES + 3) / 4) void conv_mfma_role
         if (OCB == 1) asm volatile("s_nop 7\n\ts_nop 4" ::: "memory");  // (asm MFMA results: see conv_mfma.cuh)
         // the next claim, behind the MFMAs just issued: its LDS round trip passes while they execute
         b = lds_add_rtn_lane0_sync(4 * (RCTL_MTAIL + cg), v64) >> 6;
-        if (DST == DFX_U8) {
+        if (DST == DFX_U8 || relu1) {
           // ---- u8: per value one v_fma_f32 (mode 3) or v_add_f32 + v_mul_f32 (mode 2) and one v_cvt_pk_u8_f32
           //      (RNE + [0, 255] saturation = ReLU + vcvtps2dq + vpmovusdb on the values the host admits to these
           //      modes); per pixel one store with a scalar base, no address arithmetic.  Partial tiles (CHECK):
-          //      the stores of pixels beyond the tile's end are predicated off ----
+          //      the stores of pixels beyond the tile's end are predicated off.
+          //      s8 WITH ReLU takes the same route with one v_med3_f32 more per value: max(0, f) -> vcvtps2dq ->
+          //      vpmovsdb (jit_conv_kernel.cc:352-384) lands in [0, 127], which is RNE + u8 saturation of
+          //      clamp(f, 0, 127) -- 127.0 converts to 127, anything in (126.5, 127) rounds to it as well ----
           auto fast = [&](auto mode_tag, auto check_tag) {
             constexpr int MODE = decltype(mode_tag)::value;
             constexpr bool CHECK = decltype(check_tag)::value;
@@ -568,7 +571,8 @@ __global__ __launch_bounds__(RL_THREADS, (RL_WAVES + 3) / 4) void conv_mfma_role
 #pragma unroll
               for (int cc = 0; cc < G; ++cc) {
                 const float x = __int_as_float(acc1[cc][e]);
-                const float f = MODE == 3 ? __builtin_fmaf(x, fck[cc], fbk[cc]) : __fmul_rn(__fadd_rn(x, fbk[cc]), fck[cc]);
+                float f = MODE == 3 ? __builtin_fmaf(x, fck[cc], fbk[cc]) : __fmul_rn(__fadd_rn(x, fbk[cc]), fck[cc]);
+                if (DST == DFX_S8) f = __builtin_amdgcn_fmed3f(f, 0.0f, 127.0f);
                 pk = __builtin_amdgcn_cvt_pk_u8_f32(f, cc, pk);
               }
               const unsigned off = (unsigned)pl * row_bytes;
@@ -592,7 +596,7 @@ __global__ __launch_bounds__(RL_THREADS, (RL_WAVES + 3) / 4) void conv_mfma_role
           if (nvalid == 32) { if (mode1 == 3) fast(M3{}, F{}); else fast(M2{}, F{}); }
           else { if (mode1 == 3) fast(M3{}, T{}); else fast(M2{}, T{}); }
         } else {
-          // s8 output: conv_mfma.cuh's pixel-pair emitter (optional ReLU, signed saturation; predicated stores
+          // s8 output without ReLU: conv_mfma.cuh's pixel-pair emitter (signed saturation; predicated stores
           // beyond a partial tile's end)
           int ia[G];
           v2f fb[G], fc[G];

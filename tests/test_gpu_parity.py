@@ -902,6 +902,25 @@ def test_role_specialised_kernel_scheduling(hip, oracle, tuning, geom, rounds):
     hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), "roles geom %s rounds %s" % (geom, rounds))
 
 
+def test_role_specialised_kernel_s8_routes(hip, oracle):
+    """s8 output on the role-specialised kernel: with ReLU the u8 route + a clamp to [0, 127] (the saturation must
+    be reached in the wide cases), without ReLU the signed emitter; partial tiles (13 x 17 pixels) in both."""
+    saw_127 = saw_negative = False
+    for relu1 in (True, False):
+        for wide in (False, True):
+            for pc1 in (False, True):
+                case = C.ConvCase("s8r", 3, 64, 13, 17, 64, 256, dst_dt=C.S8, relu1=relu1, wide=wide, per_channel1=pc1)
+                data = C.generate(case)
+                if wide:
+                    data["scales1"] = data["scales1"] * np.float32(8.0)   # push the outputs into the saturation
+                got, info = hip.hip_conv(case, data)
+                assert info.kernel_name.decode().startswith("conv_mfma_roles_kernel"), info.kernel_name
+                hip.assert_bit_equal(got, hip.oracle_conv(oracle, case, data), "roles s8 relu1=%s wide=%s" % (relu1, wide))
+                saw_127 |= relu1 and bool((got == 127).any())
+                saw_negative |= (not relu1) and bool((got < 0).any())
+    assert saw_127 and saw_negative
+
+
 def test_role_specialised_kernel_falls_back(hip, oracle, tuning):
     """what the role-specialised kernel does not take stays on conv_mfma.cuh's kernel: round-down, a negative
     conv0 scale, the exact-requant switches."""
