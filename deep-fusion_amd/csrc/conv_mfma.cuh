@@ -173,6 +173,9 @@ struct MfmaGeom {  // unit decomposition chosen by the host (dfx_api.hip)
                        // full-width row groups (th even); a tile is 2 rows x 16 columns, so that a pooling
                        // window is accumulator registers e, e+1, e+8, e+9 of one lane; dst has oh/2 x ow/2 pixels
   int lazy_queue;      // 1: a loader draws its next unit only when the slot for it is free (store-bound ops)
+  int half_from;       // unit ids >= half_from denote HALF units (th / 2 rows): id half_from + 2 i + j is half j of unit
+                       // half_from + i; total_units counts them.  INT_MAX: none.  The tail of a store-bound op: the
+                       // queue's granule is what a workgroup still holds when the queue runs dry (dfx_api.hip)
   int *queue;          // [0] next unit, [1] finished loaders; both 0 between launches
 #ifdef DFX_STAMPS
   unsigned long long *prof;  // diagnostic build only: [workgroup][wave][16] cycle sums
@@ -571,26 +574,36 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
   };
   // unit -> (image, unit row, unit column) with multiply-high instead of integer division (a unit id is
   // < 2^31 / 64, far inside the range where ceil(2^32 / d) is exact)
-  auto unit_split = [&](int unit, int &n, int &uyi, int &uxi) {
+  // (hrow, hth: first row inside the unit and rows of the piece the id denotes -- the whole unit, or one half)
+  auto unit_split = [&](int unit, int &n, int &uyi, int &uxi, int &hrow, int &hth) {
+    hrow = 0;
+    hth = g.th;
+    if (unit >= g.half_from) {
+      const int v = unit - g.half_from;
+      unit = g.half_from + (v >> 1);
+      hth = g.th >> 1;
+      hrow = (v & 1) * hth;
+    }
     n = g.upi_magic ? (int)__umulhi((unsigned)unit, g.upi_magic) : unit;
     const int u = unit - n * upi;
     uyi = g.ux_magic ? (int)__umulhi((unsigned)u, g.ux_magic) : u;
     uxi = u - uyi * g.ux;
   };
+  // (a half unit's halo tile is loaded like a whole unit's, th + 2 rows from its own first row: one row too many)
   auto unit_origin = [&](int unit, const uint8_t *&src_n, int &y0, int &x0) {
-    int n, uyi, uxi;
-    unit_split(unit, n, uyi, uxi);
-    y0 = uyi * g.th - a.pt;
+    int n, uyi, uxi, hrow, hth;
+    unit_split(unit, n, uyi, uxi, hrow, hth);
+    y0 = uyi * g.th + hrow - a.pt;
     x0 = uxi * g.tw - a.pl;
     src_n = a.src + (size_t)n * a.ih * a.iw * IC;
   };
 
   // what a compute wave needs to know about a unit (the loader computes it once per unit)
   auto unit_info = [&](int unit, int &pix0, int &thtw, int &tprm) {
-    int n, uyi, uxi;
-    unit_split(unit, n, uyi, uxi);
-    const int y0 = uyi * g.th, x0 = uxi * g.tw;
-    const int th = min(g.th, a.oh - y0), tw = min(g.tw, a.ow - x0);
+    int n, uyi, uxi, hrow, hth;
+    unit_split(unit, n, uyi, uxi, hrow, hth);
+    const int y0 = uyi * g.th + hrow, x0 = uxi * g.tw;
+    const int th = max(0, min(hth, a.oh - y0)), tw = min(g.tw, a.ow - x0);  // (0 rows: the second half of a bottom unit)
     const int tpr = g.pool ? (tw + 15) >> 4 : (tw + 31) >> 5;
     pix0 = g.pool ? (n * (a.oh >> 1) + (y0 >> 1)) * (a.ow >> 1) + (x0 >> 1)  // first POOLED pixel of the unit
                   : (n * a.oh + y0) * a.ow + x0;

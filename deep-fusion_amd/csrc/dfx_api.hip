@@ -95,7 +95,7 @@ static size_t dt_size(int dt) { return (dt == DFX_F32 || dt == DFX_S32) ? 4 : 1;
 // ---- testing / tuning switches.  The environment is read ONCE, when the
 //      library is first used; tests flip a switch afterwards with dfx_debug_set_tuning(). ----
 namespace {
-const char *const kTuningKeys[] = {"DFX_MAX_TH", "DFX_FORCE_GEOM", "DFX_STATIC_ROUNDS", "DFX_NO_FAST", "DFX_NO_MAGIC", "DFX_NO_LAZY", "DFX_NO_ROLES", "DFX_STORE_BOUND_BYTES",
+const char *const kTuningKeys[] = {"DFX_MAX_TH", "DFX_FORCE_GEOM", "DFX_STATIC_ROUNDS", "DFX_NO_FAST", "DFX_NO_MAGIC", "DFX_NO_LAZY", "DFX_HALF_UNITS", "DFX_NO_ROLES", "DFX_STORE_BOUND_BYTES",
                                    "DFX_STREAM_PXB", "DFX_STREAM_BLOCKING", "DFX_STREAM_PLANES", "DFX_STREAM_OCC_PAR",
                                    "DFX_STREAM_DIRECT", "DFX_STREAM_PW", "DFX_DIRECT_NPB", "DFX_DIRECT_NW", "DFX_DIRECT_WO1", "DFX_STREAM_GRID", "DFX_DEBUG_PTRS",
                                    "DEEPFUSION_PROFILE"};
@@ -1033,6 +1033,27 @@ int dfx_conv_create(const dfx_conv_desc *desc, dfx_conv_t **out) {
         h->geom.static_rounds = 2;
       }
       if (const char *e = tune("DFX_STATIC_ROUNDS")) h->geom.static_rounds = std::min(rounds, std::max(0, atoi(e)));  // tuning aid
+      // Store-bound ops, the tail: a loader stream works through a unit in ~1/7 of the launch (headline: 10.7 us)
+      // and a workgroup still holds up to four when the queue runs dry, so workgroups finish up to ~20 us apart
+      // (stamps: a CU is idle 8.4 us = 10.5 % of the span before the kernel ends).  Handing out the last units as
+      // two half units each (ids >= half_from, MfmaGeom::half_from: the same tiles, the same bytes, half the
+      // granule) pays only where a HALF unit still brings >= 7 tiles for the 14 compute waves: VGG conv1_2 f32
+      // (224-pixel rows) 325.5-325.9 us with the last 2048 units split against 327.2-328.6; the headline's
+      // half units have 2 tiles and cost it 0.3 % (256 units split) to 13 % (2048): profiles/r03/ab_half_units.txt.
+      // DFX_HALF_UNITS = number of units to split (0: none) overrides the rule.
+      h->geom.half_from = 0x7fffffff;
+      if (h->geom.lazy_queue && !h->geom.pool && h->geom.th % 2 == 0) {
+        const int half_tiles = h->geom.linear ? ((h->geom.th / 2) * h->geom.tw + 31) / 32 : (h->geom.th / 2) * (h->geom.tw / 32);
+        long long nh = half_tiles >= 7 ? 4LL * teams : 0;
+        if (const char *e = tune("DFX_HALF_UNITS")) nh = std::max(0, atoi(e));
+        nh = std::min<long long>(nh, (long long)h->geom.total_units - (long long)(h->geom.static_rounds + 1) * teams);
+        if (nh > 0) {
+          h->geom.half_from = h->geom.total_units - (int)nh;
+          h->geom.total_units += (int)nh;
+          h->geom.claim_limit =
+              (int)std::min<long long>(0x7ffffff0LL, (long long)h->geom.ntu * ((long long)h->geom.total_units + 4));
+        }
+      }
     }
 #ifdef DFX_STAMPS
     // [grid][16 waves][16] sums, then [grid][16 waves][8 events][4] timeline words

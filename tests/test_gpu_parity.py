@@ -120,13 +120,15 @@ SCHED_CASES = [
     C.ConvCase("sched_u8", 80, 64, 56, 56, 64, 256, dst_dt=C.U8),
     # many units per loader (three static rounds, then the queue), partial last round
     C.ConvCase("sched_f32", 9, 32, 120, 200, 64, 0, dst_dt=C.F32),
+    # store-bound with an odd number of output rows: the bottom unit of an image has one row, its second HALF none
+    C.ConvCase("sched_odd", 80, 64, 55, 56, 64, 256, dst_dt=C.S32),
 ]
 
 
 @pytest.mark.parametrize("case", SCHED_CASES, ids=lambda c: c.ident())
 def test_resident_kernel_unit_scheduling(hip, oracle, tuning, case):
     """how units reach the loaders (conv_mfma.cuh: static stream-major split, lazy queue draws for
-    store-bound ops, eager queue) must not change a byte: every mode is compared with the default
+    store-bound ops, eager queue, the last units handed out as halves) must not change a byte: every mode is compared with the default
     run, and the default run's first images with the oracle."""
     data = C.generate(case)
     ref_run, info = hip.hip_conv(case, data)
@@ -135,7 +137,8 @@ def test_resident_kernel_unit_scheduling(hip, oracle, tuning, case):
     sub = dict(data, src=data["src"][:n])
     hip.assert_bit_equal(ref_run[:n], hip.oracle_conv(oracle, replace(case, bs=n), sub), info.kernel_name.decode())
     for key, val in (("DFX_NO_LAZY", "1"), ("DFX_STATIC_ROUNDS", "1"), ("DFX_STATIC_ROUNDS", "2"),
-                     ("DFX_STATIC_ROUNDS", "99"), ("DFX_FORCE_GEOM", "4,56" if case.iw == 56 else "3,32")):
+                     ("DFX_STATIC_ROUNDS", "99"), ("DFX_FORCE_GEOM", "4,56" if case.iw == 56 else "3,32"),
+                     ("DFX_HALF_UNITS", "0"), ("DFX_HALF_UNITS", "77"), ("DFX_HALF_UNITS", "1000000")):
         tuning.setenv(key, val)
         got, _ = hip.hip_conv(case, data)
         tuning.undo()
