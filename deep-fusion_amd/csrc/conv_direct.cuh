@@ -209,9 +209,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
     return q;
   };
   const float r_tq1 = 1.0f / __int2float_rn(tile_q1), r_lhw = 1.0f / __int2float_rn(lhw), r_lw = 1.0f / __int2float_rn(g.lw);
-  auto tq_fill = [&](int (&tqp)[DK_TQ], int qbase) {
+  auto tq_fill = [&](auto &tqp, int qbase) {
+    constexpr int N_ = (int)(sizeof(tqp) / sizeof(int));
 #pragma unroll
-    for (int i = 0; i < DK_TQ; ++i) {
+    for (int i = 0; i < N_; ++i) {
       const int q = min(qbase + tid + DK_THREADS * i, tile_q - 1);
       int ql, r, lx;
       const int pl = divmod(q, tile_q1, r_tq1, ql);
@@ -225,9 +226,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
   v4i tv[DK_TQ];
   int tv_ok = 0;
   // (branch-free loads: hipcc waits vmcnt(0) inside a branch around a load)
-#define DK_T_ISSUE(TQP, QB, N0, IY0, IX0, NIMG)                                         \
+#define DK_T_ISSUE(TV, TQP, QB, N0, IY0, IX0, NIMG)                                     \
   do {                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < DK_TQ; ++i) {                                 \
+    _Pragma("unroll") for (int i = 0; i < (int)(sizeof(TQP) / sizeof(int)); ++i) {      \
       const int q_ = (QB) + tid + DK_THREADS * i;                                       \
       const int pl_ = (TQP[i] >> 28) & 15, img_ = (TQP[i] >> 20) & 255;                 \
       const int ly_ = (TQP[i] >> 10) & 1023, lx_ = TQP[i] & 1023;                       \
@@ -238,19 +239,19 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
       const int n_ = min((N0) + img_, a.bs - 1), y_ = min(max(iy_, 0), a.ih - 1);       \
       const int x_ = min(max(ix_, 0), a.iw - 1), c_ = min(cb_, a.ic - 16);              \
       const long long o_ = (((long long)n_ * a.ih + y_) * a.iw + x_) * a.ic + c_;       \
-      tv[i] = *reinterpret_cast<const v4i *>(a.src + DK_CHK(1, o_, 16, g.src_bytes));   \
+      TV[i] = *reinterpret_cast<const v4i *>(a.src + DK_CHK(1, o_, 16, g.src_bytes));   \
       tv_ok = ok_ ? (tv_ok | (1 << i)) : (tv_ok & ~(1 << i));                           \
     }                                                                                   \
   } while (0)
-#define DK_T_COMMIT(TQP, QB)                                                            \
+#define DK_T_COMMIT(TV, TQP, QB)                                                        \
   do {                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < DK_TQ; ++i) {                                 \
+    _Pragma("unroll") for (int i = 0; i < (int)(sizeof(TQP) / sizeof(int)); ++i) {      \
       const int q_ = (QB) + tid + DK_THREADS * i;                                       \
       const int pl_ = (TQP[i] >> 28) & 15, img_ = (TQP[i] >> 20) & 255;                 \
       const int ly_ = (TQP[i] >> 10) & 1023, lx_ = TQP[i] & 1023;                       \
       const int lo_ = q_ < tile_q ? pl_ * g.plane_bytes + img_ * g.img_pitch + ly_ * g.row_pitch + lx_ * DK_POS + 16 * (q_ & 3) \
                                   : g.n_planes * g.plane_bytes; /* dump slot */          \
-      *reinterpret_cast<v4i *>(tile0 + lo_) = ((tv_ok >> i) & 1) ? tv[i] ^ x80 : x80;   \
+      *reinterpret_cast<v4i *>(tile0 + lo_) = ((tv_ok >> i) & 1) ? TV[i] ^ x80 : x80;   \
     }                                                                                   \
   } while (0)
 
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
     v4i wr[DK_RD];
     const bool even0 = nkb0 % DK_RD == 0;
     // ---- stage the whole halo tile (all planes) ----
-    DK_T_ISSUE(tq_pos, 0, ug.n0, ug.iy0, ug.ix0, ug.nimg);
+    DK_T_ISSUE(tv, tq_pos, 0, ug.n0, ug.iy0, ug.ix0, ug.nimg);
     // (slot -> image, row, column of the unit: f32-reciprocal quotients as in the staging table; the integer
     // division sequences of the slot table and of conv0's PXW fragment bases were ~350 instructions per unit)
     const float r_px = 1.0f / __int2float_rn(thc * twc), r_tw = 1.0f / __int2float_rn(twc);
@@ -329,15 +330,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
         pxoff[slot] = (slot < npx || (QM != 0 && !DK_QM_TRANSPOSE)) ? (unsigned)(((ug.n0 + img) * a.oh + ug.y0 + ty) * a.ow + ug.x0 + tx) * row_bytes
                                                                    : 0xffffffffu;
     }
-    DK_T_COMMIT(tq_pos, 0);
+    DK_T_COMMIT(tv, tq_pos, 0);
     // the part of the tile beyond the first DK_TQ granules per thread (stride-2 tiles, many planes): further batches
-    // of DK_TQ loads each, positions computed on the fly.  (Until late round 3 this was a loop of single dependent
-    // load -> store pairs with three integer divisions each: 744 of stride-2 res3's 2280 granules went through it.)
-    for (int qb = DK_THREADS * DK_TQ; qb < tile_q; qb += DK_THREADS * DK_TQ) {
-      int tq2[DK_TQ];
+    // of DK_TQ2 loads each, positions computed on the fly.  (Until late round 3 this was a loop of single dependent
+    // load -> store pairs with three integer divisions each: 744 of stride-2 res3's 2280 granules went through it.
+    // Then batches of DK_TQ = 6: res3's 1680-granule tile has 144 granules beyond the first 1536, and all 256 threads
+    // walked a whole second batch for them -- ~570 vector instructions per wave and unit, about a fifth of all it
+    // issued; with batches of 2 it is a third of that.)
+    constexpr int DK_TQ2 = 2;
+    for (int qb = DK_THREADS * DK_TQ; qb < tile_q; qb += DK_THREADS * DK_TQ2) {
+      int tq2[DK_TQ2];
+      v4i tv2[DK_TQ2];
       tq_fill(tq2, qb);
-      DK_T_ISSUE(tq2, qb, ug.n0, ug.iy0, ug.ix0, ug.nimg);
-      DK_T_COMMIT(tq2, qb);
+      DK_T_ISSUE(tv2, tq2, qb, ug.n0, ug.iy0, ug.ix0, ug.nimg);
+      DK_T_COMMIT(tv2, tq2, qb);
     }
     if (first_unit) {  // the constants' LDS-DMA (see above)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -499,30 +505,33 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
           DK_LOAD_FB(1);
         }
         v16i acc[PXW];
+        // START_C: the specialised kernels' 3x3 path hands the start values to the first k-block's MFMAs as their C
+        // operand instead of copying them into every accumulator first (16 v_mov per pixel block and output block)
+        constexpr bool START_C = T9 && QM != 0;
+        v16i st = zero16;
         if (QM != 0 || g.m0) {  // "fma": start from bits(2^23) + comp + bias of this lane's 16 channels (comp slot of the constants)
-          v16i st;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const v4i iv = *reinterpret_cast<const v4i *>(comp0 + ob * 32 + 8 * q + 4 * h);
             st[4 * q + 0] = iv[0]; st[4 * q + 1] = iv[1]; st[4 * q + 2] = iv[2]; st[4 * q + 3] = iv[3];
           }
+        }
+        if (!START_C) {
 #pragma unroll
           for (int p = 0; p < PXW; ++p) acc[p] = st;
-        } else {
-#pragma unroll
-          for (int p = 0; p < PXW; ++p) acc[p] = zero16;
         }
         DKF();
         int kb0 = 0;
         if constexpr (T9) {
-          for (; kb0 < nkb0; kb0 += DK_RD) {
+          auto round9 = [&](auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
             const int nxt = icb_r + 1 == g.icb ? 0 : icb_r + 1;
             const int dnext = ((nxt >> 1) - (icb_r >> 1)) * g.plane_bytes + ((nxt & 1) - (icb_r & 1)) * 32;
             const int rbase = (min(f_ob, ob_last) * nkb0 + f_kb0) << 10;
 #pragma unroll
             for (int i = 0; i < DK_RD; ++i) {
 #pragma unroll
-              for (int p = 0; p < NF; ++p) acc[p] = mfma_i8(wr[i], fb[i % 3][p], acc[p]);  // D0[oc][px]
+              for (int p = 0; p < NF; ++p) acc[p] = mfma_i8(wr[i], fb[i % 3][p], (FIRST && i == 0) ? st : acc[p]);  // D0[oc][px]
               DKF();
               {
                 const int t = (i + 2) % 9, rr = t / 3, dx = t % 3;  // the tap two steps ahead (7, 8: the next round's 0, 1); constants once unrolled
@@ -532,7 +541,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
               }
               DKF();
 #pragma unroll
-              for (int p = NF; p < PXW; ++p) acc[p] = mfma_i8(wr[i], fb[i % 3][p], acc[p]);
+              for (int p = NF; p < PXW; ++p) acc[p] = mfma_i8(wr[i], fb[i % 3][p], (FIRST && i == 0) ? st : acc[p]);
               DKF();
               wr[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(w0rs, (int)lane16, rbase + i * 1024, 0));
               if (i == 0 || i == 3 || i == 6) {  // row i / 3 has issued its last prefetch of this round
@@ -544,7 +553,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
             icb_r = nxt;
             f_kb0 += DK_RD;
             if (f_kb0 == nkb0) { f_kb0 = 0; f_ob += WO; }
+          };
+          if constexpr (START_C) {  // (nkb0 is a positive multiple of nine on this path)
+            round9(TT{});
+            kb0 = DK_RD;
           }
+          for (; kb0 < nkb0; kb0 += DK_RD) round9(FF{});
         }
         for (; !T9 && kb0 + DK_RD <= nkb0; kb0 += DK_RD) {
 #pragma unroll
@@ -654,23 +668,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
             mid_n[p] = mid + (32 * (pbn + p) + l31) * g.mid_stride + h * 16;
           }
           v16i acc1[PX1][G];
-          {
-            const int m1s = QM != 0 ? MAGIC1_BITS : 0;  // "magic": the accumulator's bits read as 1/(2 pi) + raw * 2^-26
-            const v16i st1 = {m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s};
-#pragma unroll
-            for (int p = 0; p < PX1; ++p)
-#pragma unroll
-              for (int cc = 0; cc < G; ++cc) acc1[p][cc] = st1;
-          }
+          // "magic": the accumulator's bits read as 1/(2 pi) + raw * 2^-26.  The start value is the C operand of the
+          // pass's first MFMAs (an inline constant: no register, no v_mov -- 16 per accumulator and pass otherwise)
+          constexpr int m1s = QM != 0 ? MAGIC1_BITS : 0;
+          const v16i st1 = {m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s, m1s};
           DKF();
           constexpr int NM = PX1 * G, NF1 = NM < 2 ? NM : 2;
-          for (int b0 = 0; b0 < g.ocb; b0 += RD1) {
+          auto kround1 = [&](int b0, auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
 #pragma unroll
             for (int i = 0; i < RD1; ++i) {
               const int blk = b0 + i;
 #pragma unroll
               for (int m = 0; m < NF1; ++m)
-                acc1[m % PX1][m / PX1] = mfma_i8(fa[i & 1][m % PX1], wr1[i][m / PX1], acc1[m % PX1][m / PX1]);
+                acc1[m % PX1][m / PX1] = mfma_i8(fa[i & 1][m % PX1], wr1[i][m / PX1], (FIRST && i == 0) ? st1 : acc1[m % PX1][m / PX1]);
               DKF();
               {  // the next k-block's pixel fragments; behind the last one: the next pass's first
                 const bool last = blk + 1 == g.ocb;
@@ -681,7 +692,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
               DKF();
 #pragma unroll
               for (int m = NF1; m < NM; ++m)
-                acc1[m % PX1][m / PX1] = mfma_i8(fa[i & 1][m % PX1], wr1[i][m / PX1], acc1[m % PX1][m / PX1]);
+                acc1[m % PX1][m / PX1] = mfma_i8(fa[i & 1][m % PX1], wr1[i][m / PX1], (FIRST && i == 0) ? st1 : acc1[m % PX1][m / PX1]);
               DKF();
               {
                 const unsigned idx = r1_next();
@@ -690,7 +701,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
               }
               DKF();
             }
-          }
+          };
+          kround1(0, TT{});  // (ocb is a positive multiple of RD1)
+          for (int b0 = RD1; b0 < g.ocb; b0 += RD1) kround1(b0, FF{});
           DFX_STAMP(t7);
           DFX_ACC(4, t7 - t6);  // conv1 K loop
           // ---- requant 1 + store (constants from LDS: a global load here would wait for the ring) ----
