@@ -58,6 +58,14 @@
 //  * 3x3 fast path (T9 below): no scalar bookkeeping in the conv0 K loop -- the generic loop's ~30 scalar
 //    instructions per k-block made res5 (one MFMA per k-block) scalar-issue bound.  res5 43.1 -> 38.1 us, res4
 //    29.9 -> 27.4, res3 35.3 -> 33.1.
+//  * vector-instruction diet (late round 3; PMC: res3 issued 8.4 M non-MFMA vector instructions per launch where the
+//    two requants need 2.0 M): accumulator start values as the C operand of each chain's first MFMA (an inline
+//    constant for conv1: 16 v_mov per accumulator and pass gone), the tile's granules beyond the first 6 per thread
+//    in batches of 2 (res3's 144 left-over granules cost every thread a whole batch of 6), the conv0 fragment bases
+//    from the slot table instead of two divisions per pixel block: res3 33.5 -> 32.1 us, res3s2 41.8 -> 39.4,
+//    vgg3 124.0 -> 117.6, res4 27.8 -> 27.2 (profiles/r03/ab_direct_valu_trims.txt).  Tried on top and dropped:
+//    the tile's loads as buffer loads with 32-bit offsets relative to the unit's first image and no coordinate
+//    clamps (2-7 % SLOWER, same file).
 // Where the time goes now (stamps build, profiles/r03/stamps_direct_12_after_fast_path.txt): res4 conv0 K loop 38 %
 // of a unit (the matrix pipe is ~100 % busy inside it), conv1 23 % (77 %), tile staging 11 %, store epilogue 9.5 %,
 // barrier imbalance 8 %; ~5.6 k cycles (10 %) from kernel entry to the first unit.  The weight stream is the floor
@@ -157,7 +165,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
   DFX_STAMP(t_entry);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char *const tile0 = smem;
-  unsigned *pxoff = reinterpret_cast<unsigned *>(smem + g.off_pxoff);
+  unsigned *pxoff = reinterpret_cast<unsigned *>(smem + g.off_pxoff);  // [32 NPB] dst byte offset of the slot's pixel
+  int *fboff = reinterpret_cast<int *>(pxoff + 32 * NPB);                // [32 NPB] tile byte offset of its input position
   unsigned char *mid = smem + g.off_mid;
   float *cst0 = reinterpret_cast<float *>(smem + g.off_cst);
 
@@ -326,9 +335,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
       const int ty = divmod(r, twc, r_tw, tx);
       // (pc is clamped to the unit's last pixel.  QM != 0: empty slots repeat that pixel's offset -- see the store
       // epilogue; otherwise they are marked)
-      if (h == 0)
+      if (h == 0) {
         pxoff[slot] = (slot < npx || (QM != 0 && !DK_QM_TRANSPOSE)) ? (unsigned)(((ug.n0 + img) * a.oh + ug.y0 + ty) * a.ow + ug.x0 + tx) * row_bytes
                                                                    : 0xffffffffu;
+        // (the conv0 waves used to redo the slot's two divisions for each of their PXW pixel blocks)
+        fboff[slot] = img * g.img_pitch + ty * a.sh * g.row_pitch + tx * a.sw * DK_POS;
+      }
     }
     DK_T_COMMIT(tv, tq_pos, 0);
     // the part of the tile beyond the first DK_TQ granules per thread (stride-2 tiles, many planes): further batches
@@ -359,11 +371,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
 #pragma unroll
     for (int p = 0; p < PXW; ++p) {
       const int slot = 32 * (wp * PXW + p) + l31;
-      const int pc = min(slot, npx - 1);
-      int r, tx;
-      const int img = divmod(pc, thc * twc, r_px, r);
-      const int ty = divmod(r, twc, r_tw, tx);
-      fbyte[p] = img * g.img_pitch + ty * a.sh * g.row_pitch + tx * a.sw * DK_POS + 16 * h;
+      fbyte[p] = fboff[slot] + 16 * h;
       mid_w[p] = mid + slot * g.mid_stride + h * 16;
     }
     // requant 0 -> u8 -> mid, in the 1x1 stage's k order: byte 16h + 4q + i of block ob = channel 32 ob + 8q + 4h + i.

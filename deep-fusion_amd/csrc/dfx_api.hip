@@ -481,7 +481,7 @@ static bool pick_direct_geometry(const dfx_conv_desc &d, int NW, int WO, int G, 
   const size_t stage_bytes = (G == 4 && dt_size(d.dst_dt) == 1) ? (size_t)NW * DK_STAGE : 0;
   // (`mid`: the u8 intermediate / the 1-byte output rows; an unfused op with 4-byte output stages 32 px x 128 B per wave there)
   const size_t mid_bytes = std::max((size_t)M * g.mid_stride, (d.oc1x1 == 0 && dt_size(d.dst_dt) == 4) ? (size_t)NW * 32 * 144 : (size_t)0);
-  const size_t fixed = 4 * M + mid_bytes + cst_bytes;
+  const size_t fixed = 8 * M + mid_bytes + cst_bytes;  // (8 M: the slot tables pxoff and fboff)
   const size_t lds_max = 163840;
   g.unfused = d.oc1x1 == 0 ? 1 : 0;
   if ((long long)d.bs * d.oh * d.ow * (d.oc1x1 ? d.oc1x1 : d.oc) * (long long)dt_size(d.dst_dt) >= (1LL << 32) - 16 ||
@@ -552,7 +552,7 @@ static bool pick_direct_geometry(const dfx_conv_desc &d, int NW, int WO, int G, 
   }
   g.plane_bytes = g.ni * g.img_pitch;
   g.off_pxoff = (int)round16(std::max((size_t)g.n_planes * (size_t)g.plane_bytes + 16, stage_bytes));
-  g.off_mid = g.off_pxoff + 4 * M;
+  g.off_mid = g.off_pxoff + 8 * M;
   g.off_cst = g.off_mid + (int)round16(mid_bytes);
   lds = g.off_cst + (int)cst_bytes;
   g.fast = 0;
