@@ -237,6 +237,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
   // (branch-free loads: hipcc waits vmcnt(0) inside a branch around a load)
 #define DK_T_ISSUE(TV, TQP, QB, N0, IY0, IX0, NIMG)                                     \
   do {                                                                                  \
+    /* scalar base of the unit's first image + a 32-bit per-lane offset (the host admits only units whose images  \
+       span < 2^31 bytes): no 64-bit per-lane multiply-adds */                                                   \
+    const long long img_b_ = (long long)a.ih * a.iw * a.ic;                             \
+    const uint8_t *ub_ = a.src + (long long)(N0) * img_b_;                              \
+    const int nmax_ = a.bs - 1 - (N0);                                                  \
     _Pragma("unroll") for (int i = 0; i < (int)(sizeof(TQP) / sizeof(int)); ++i) {      \
       const int q_ = (QB) + tid + DK_THREADS * i;                                       \
       const int pl_ = (TQP[i] >> 28) & 15, img_ = (TQP[i] >> 20) & 255;                 \
@@ -245,10 +250,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_direct_kernel(C
       const bool ok_ = q_ < tile_q && img_ < (NIMG) && iy_ >= 0 && iy_ < a.ih && ix_ >= 0 && \
                        ix_ < a.iw && cb_ < a.ic;                                        \
       /* always an in-range address (clamped coordinates); padding is zeroed at commit */ \
-      const int n_ = min((N0) + img_, a.bs - 1), y_ = min(max(iy_, 0), a.ih - 1);       \
+      const int n_ = min(img_, nmax_), y_ = min(max(iy_, 0), a.ih - 1);                 \
       const int x_ = min(max(ix_, 0), a.iw - 1), c_ = min(cb_, a.ic - 16);              \
-      const long long o_ = (((long long)n_ * a.ih + y_) * a.iw + x_) * a.ic + c_;       \
-      TV[i] = *reinterpret_cast<const v4i *>(a.src + DK_CHK(1, o_, 16, g.src_bytes));   \
+      const unsigned o_ = (unsigned)(((n_ * a.ih + y_) * a.iw + x_) * a.ic + c_);       \
+      (void)DK_CHK(1, (long long)(N0) * img_b_ + o_, 16, g.src_bytes);                  \
+      TV[i] = *reinterpret_cast<const v4i *>(ub_ + o_);                                 \
       tv_ok = ok_ ? (tv_ok | (1 << i)) : (tv_ok & ~(1 << i));                           \
     }                                                                                   \
   } while (0)
