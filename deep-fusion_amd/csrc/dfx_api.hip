@@ -1527,7 +1527,10 @@ int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei, const void *bia0, con
       if (fma1) mode1 = 3;
     }
     if (h->variant == DFX_VARIANT_MFMA_FUSED) {
-      if (roles) snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_mfma_roles_kernel<%d,%d,%d,%d>", ICB, OCB, NCB, d.dst_dt);
+      // (the suffix names stage 1's requant route: "fma" = one v_fma_f32 per value, admitted where the addend is exactly
+      //  representable -- power-of-two scales and a few others; "magic" = v_add_f32 + v_mul_f32)
+      if (roles) snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_mfma_roles_kernel<%d,%d,%d,%d>/%s", ICB, OCB, NCB, d.dst_dt,
+                          mode1 == 3 ? "fma" : "magic");
       else snprintf(h->kernel_name, sizeof(h->kernel_name), "conv_mfma_fused_kernel<%d,%d,%d,%d>", ICB, OCB, G, d.dst_dt);
       h->block = roles ? RL_THREADS : MFMA_THREADS;
     }
