@@ -66,6 +66,10 @@
 //    vgg3 124.0 -> 117.6, res4 27.8 -> 27.2 (profiles/r03/ab_direct_valu_trims.txt).  Tried on top and dropped:
 //    the tile's loads as buffer loads with 32-bit offsets relative to the unit's first image and no coordinate
 //    clamps (2-7 % SLOWER, same file).
+//    And: stage 1's add + mul route ("magic", taken where the scale is not a power of two: res3, res5) as ONE fma from
+//    per-channel accumulator start values -- bits(2^23) + comp + bias as in stage 0, brought in as 16-register tuples
+//    by four ds_read_b128 of an LDS table entry {v, v, v, v} per accumulator: 256 fewer vector instructions per wave
+//    and unit, 64 more LDS reads, bit-exact, and 1-2 % SLOWER (res3 33.2 -> 33.9 us, res5 38.1 -> 38.6).
 // Where the time goes now (stamps build, profiles/r03/stamps_direct_12_after_fast_path.txt): res4 conv0 K loop 38 %
 // of a unit (the matrix pipe is ~100 % busy inside it), conv1 23 % (77 %), tile staging 11 %, store epilogue 9.5 %,
 // barrier imbalance 8 %; ~5.6 k cycles (10 %) from kernel entry to the first unit.  The weight stream is the floor
