@@ -78,8 +78,8 @@
 //    in flight), and the scheduling rules below that keep all four SIMDs fed:
 //      - units are split statically and stream-major when a loader gets <= 8 of them, so that every
 //        workgroup processes the same number +-1 (the queue's granularity left 6..8 per workgroup);
-//      - all four ring slots are full when the claim loop starts (compute waves stage units 0/1 with
-//        the weights, each loader its second unit, before the only barrier);
+//      - two of the four ring slots are full when the claim loop starts (the compute waves stage units 0/1
+//        with the weights before the only barrier; each loader fetches its second unit right behind it);
 //      - a wave draws its next claim after conv0 of the current tile and looks at that tile's unit in
 //        the last store group (not a whole tile ahead: parked claims delayed the release of slots);
 //      - a wave that lags behind the other 13 raises its issue priority (the arbiter prefers the
@@ -853,8 +853,8 @@ __global__ __launch_bounds__(MFMA_THREADS, 4) void conv_mfma_fused_kernel(ConvAr
     const int j0 = coop0 ? 1 : 0;
     if (coop0) __syncthreads();
     // lazy: store-bound ops, whose workgroups run at very different speeds (their share of the HBM write
-    // bandwidth: lifetimes 100 k .. 206 k cycles on the s32 headline).  Drawing ahead -- two units per
-    // loader are staged before the barrier, one more is prefetched, one more drawn -- hands out all 3.5
+    // bandwidth: lifetimes 100 k .. 206 k cycles on the s32 headline).  Drawing ahead -- one unit per
+    // loader is staged before the barrier, the next fetched behind it, one more prefetched, one more drawn -- hands out all 3.5
     // units per loader in the first quarter of the kernel, so the queue balances nothing.  A lazy loader
     // draws when the slot for the unit is free: fast workgroups come back for more.  The ~6 us from
     // draw to published tile are covered by the three other slots (a tile takes ~16 us here).

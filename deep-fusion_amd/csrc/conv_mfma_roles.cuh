@@ -43,9 +43,9 @@
 //   End: an A wave that runs out of tiles adds itself to ADONE; a B wave whose slot stays empty after that leaves.
 //   Every spin is bounded (RL_SPIN_LIMIT / MFMA_SPIN_LIMIT).
 // The mid ring lives in the LDS area the packed 1x1 weights have in conv_mfma.cuh's LDS image.
-// Start-up: W0 + constants travel global -> LDS by LDS-DMA (no VGPR / ds_write detour), the first two units of
-// each loader stream are staged by the A / B waves in the same memory round trip (the loaders' own set-up used to
-// hold the only workgroup barrier ~3 k cycles).
+// Start-up: W0 + constants travel global -> LDS by LDS-DMA (no VGPR / ds_write detour), the first unit of
+// each loader stream is staged by the A / B waves in the same memory round trip; the loader fetches the second
+// one behind the barrier (see there for what else was tried).
 // Unit numbering is XCD-major (see `wg`): vertically neighbouring units share an L2, HBM reads 1.03 x the input
 // instead of 1.5 x (PMC FETCH_SIZE 13.3 MB x 2 against 19.2 MB x 2).
 //
