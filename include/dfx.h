@@ -192,10 +192,10 @@ int dfx_conv_set_weights(dfx_conv_t *h, const int8_t *wei_blocked, const void *b
  * host threads and on several streams at once: every launch works on its own copy of the
  * arguments and its own unit-queue slot.  There are 16 slots per handle: launches on one stream are
  * ordered anyway; with several streams a launch that finds its slot last used on ANOTHER stream first
- * waits, on the device, for that launch (a 17th concurrent launch queues behind the 1st).  An op whose
- * dfx_conv_info.kernel_name starts with "split:" (two launches through a handle-owned
- * intermediate) may be submitted the same way, but its submits are ordered among each other on the
- * device: the first launch of one waits for the second launch of the previous one. */
+ * waits, on the device, for that launch (a 17th concurrent launch queues behind the 1st).  Every op is ONE
+ * kernel launch (the two-launch "split:" ops of earlier versions are gone); dfx_conv_info.kernel_name names
+ * the kernel, for the role-specialised one also its stage-1 requant route ("/fma", "/magic"), and says so
+ * when an op runs on the scalar kernel because its dst reaches 4 GiB. */
 int dfx_conv_submit(dfx_conv_t *h, const void *src_dev, void *dst_dev, dfx_stream_t s);
 /* drop-in semantics of op::submit() (deepfusion.cc:90-103): host buffers in,
  * host buffers out, synchronous (H2D, kernel, D2H, stream sync). */
